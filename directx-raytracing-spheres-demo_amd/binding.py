@@ -1,0 +1,205 @@
+"""ctypes binding of the C-ABI (include/pt_api.h) exported by libpt_hip.so, plus a thin ``Renderer`` convenience
+class shaped like the reference's pass object (Raytracing::SetConstants / Render, Source/Raytracing.ixx:92-112).
+
+No CPU fallback: if the library is absent or there is no GPU, construction raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .types import (BVH_NODE_DTYPE, PtAccelInfo, PtCamera, PtConfig, PtGraphicsSettings, PtRect, PtSceneData, PtStats)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+
+STATUS = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR_HIP", 4: "PT_ERR_STATE", 5: "PT_ERR_UNSUPPORTED", 6: "PT_ERR_OOM"}
+
+# every symbol include/pt_api.h declares
+API_SYMBOLS = [
+    "pt_create", "pt_destroy", "pt_set_scene", "pt_build_accel", "pt_set_camera", "pt_set_constants", "pt_render",
+    "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_trace_rays", "pt_accel_download",
+    "pt_accel_download_order", "pt_lbvh_build_host", "pt_set_profiling", "pt_synchronize", "pt_last_error", "pt_version",
+]
+
+
+class PtError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS.get(status, status)}: {message}")
+        self.status = status
+
+
+def hip_library_path():
+    return os.path.join(_PKG, "libpt_hip.so")
+
+
+class HipLib:
+    def __init__(self, path=None):
+        path = path or hip_library_path()
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not built: the HIP extension is required (no CPU fallback)")
+        self.lib = lib = C.CDLL(path)
+        vp, u32 = C.c_void_p, C.c_uint32
+        lib.pt_create.restype = C.c_int
+        lib.pt_create.argtypes = [C.POINTER(PtConfig), C.POINTER(vp)]
+        lib.pt_destroy.restype = None
+        lib.pt_destroy.argtypes = [vp]
+        lib.pt_set_scene.restype = C.c_int
+        lib.pt_set_scene.argtypes = [vp, vp, vp, u32, C.POINTER(PtSceneData)]
+        lib.pt_build_accel.restype = C.c_int
+        lib.pt_build_accel.argtypes = [vp, C.POINTER(PtAccelInfo)]
+        lib.pt_set_camera.restype = C.c_int
+        lib.pt_set_camera.argtypes = [vp, C.POINTER(PtCamera)]
+        lib.pt_set_constants.restype = C.c_int
+        lib.pt_set_constants.argtypes = [vp, C.POINTER(PtGraphicsSettings)]
+        lib.pt_render.restype = C.c_int
+        lib.pt_render.argtypes = [vp, C.POINTER(PtRect), vp, C.c_int, C.POINTER(PtStats)]
+        lib.pt_set_partition.restype = C.c_int
+        lib.pt_set_partition.argtypes = [vp, u32, u32]
+        lib.pt_tiles_count.restype = u32
+        lib.pt_tiles_count.argtypes = [vp, u32]
+        lib.pt_render_tiles.restype = C.c_int
+        lib.pt_render_tiles.argtypes = [vp, vp, C.POINTER(PtStats)]
+        lib.pt_unpack_tiles.restype = C.c_int
+        lib.pt_unpack_tiles.argtypes = [vp, vp, u32, vp]
+        lib.pt_trace_rays.restype = C.c_int
+        lib.pt_trace_rays.argtypes = [vp, vp, vp, u32, C.c_float, C.c_int, vp, vp]
+        lib.pt_accel_download.restype = C.c_int
+        lib.pt_accel_download.argtypes = [vp, vp, u32]
+        lib.pt_accel_download_order.restype = C.c_int
+        lib.pt_accel_download_order.argtypes = [vp, vp, u32]
+        lib.pt_lbvh_build_host.restype = C.c_int
+        lib.pt_lbvh_build_host.argtypes = [vp, u32, vp, vp, C.POINTER(u32)]
+        lib.pt_set_profiling.restype = C.c_int
+        lib.pt_set_profiling.argtypes = [vp, C.c_int]
+        lib.pt_synchronize.restype = C.c_int
+        lib.pt_synchronize.argtypes = [vp]
+        lib.pt_last_error.restype = C.c_char_p
+        lib.pt_last_error.argtypes = [vp]
+        lib.pt_version.restype = C.c_char_p
+        lib.pt_version.argtypes = []
+
+
+    def lbvh_build_host(self, spheres):
+        """Host LBVH builder (no GPU needed) -> (nodes[BVH_NODE_DTYPE], sorted_id, depth)."""
+        spheres = np.ascontiguousarray(spheres)
+        n = len(spheres)
+        nodes = np.zeros(max(n - 1, 0), dtype=BVH_NODE_DTYPE)
+        order = np.zeros(n, dtype=np.uint32)
+        depth = C.c_uint32(0)
+        st = self.lib.pt_lbvh_build_host(spheres.ctypes.data, n, nodes.ctypes.data if n > 1 else None, order.ctypes.data, C.byref(depth))
+        if st != 0:
+            raise PtError(st, "pt_lbvh_build_host")
+        return nodes, order, depth.value
+
+
+_hip = None
+
+
+def load_hip():
+    global _hip
+    if _hip is None:
+        _hip = HipLib()
+    return _hip
+
+
+class Renderer:
+    """One PtContext.  Methods mirror the C-ABI one to one; errors raise PtError with pt_last_error()."""
+
+    def __init__(self, device=0, flags=0, stream=0, tile_size=0, lib=None):
+        self._lib = (lib or load_hip()).lib
+        cfg = PtConfig(device=device, tile_size=tile_size, stream=stream, flags=flags)
+        ctx = C.c_void_p()
+        st = self._lib.pt_create(C.byref(cfg), C.byref(ctx))
+        if st != 0:
+            raise PtError(st, "pt_create failed (a HIP device is required; there is no CPU fallback)")
+        self._ctx = ctx
+        self.accel = None
+        self._gs = None
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.pt_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != 0:
+            raise PtError(st, self._lib.pt_last_error(self._ctx).decode())
+
+    def set_scene(self, spheres, materials, scene_data, build=True):
+        spheres = np.ascontiguousarray(spheres)
+        materials = np.ascontiguousarray(materials)
+        assert spheres.dtype.itemsize == 16 and materials.dtype.itemsize == 64 and len(spheres) == len(materials)
+        self._check(self._lib.pt_set_scene(self._ctx, spheres.ctypes.data, materials.ctypes.data, len(spheres), C.byref(scene_data)))
+        return self.build_accel() if build else None
+
+    def build_accel(self):
+        info = PtAccelInfo()
+        self._check(self._lib.pt_build_accel(self._ctx, C.byref(info)))
+        self.accel = info
+        return info
+
+    def set_camera(self, camera):
+        self._check(self._lib.pt_set_camera(self._ctx, C.byref(camera)))
+
+    def set_constants(self, gs):
+        self._check(self._lib.pt_set_constants(self._ctx, C.byref(gs)))
+        self._gs = gs
+
+    def set_partition(self, rank, world):
+        self._check(self._lib.pt_set_partition(self._ctx, rank, world))
+
+    def tiles_count(self, rank):
+        return int(self._lib.pt_tiles_count(self._ctx, rank))
+
+    def set_profiling(self, enabled):
+        self._check(self._lib.pt_set_profiling(self._ctx, 1 if enabled else 0))
+
+    def synchronize(self):
+        self._check(self._lib.pt_synchronize(self._ctx))
+
+    def render(self, rect=None, want_stats=True):
+        """Render to a host numpy array (h, w, 4) float32.  rect = (x, y, w, h) or None for the full frame."""
+        if rect is None:
+            rect = (0, 0, self._gs.RenderSize[0], self._gs.RenderSize[1])
+        r = PtRect(*rect)
+        out = np.empty((r.h, r.w, 4), dtype=np.float32)
+        stats = PtStats()
+        self._check(self._lib.pt_render(self._ctx, C.byref(r), out.ctypes.data, 0, C.byref(stats) if want_stats else None))
+        return out, stats
+
+    def render_device(self, out_ptr, rect=None, want_stats=False):
+        """Render into device memory (e.g. a torch CUDA tensor's data_ptr()); asynchronous unless want_stats."""
+        r = PtRect(*rect) if rect is not None else None
+        stats = PtStats()
+        self._check(self._lib.pt_render(self._ctx, C.byref(r) if r is not None else None, C.c_void_p(out_ptr), 1, C.byref(stats) if want_stats else None))
+        return stats
+
+    def render_tiles(self, out_ptr, want_stats=False):
+        stats = PtStats()
+        self._check(self._lib.pt_render_tiles(self._ctx, C.c_void_p(out_ptr), C.byref(stats) if want_stats else None))
+        return stats
+
+    def unpack_tiles(self, gathered_ptr, max_tiles_per_rank, frame_ptr):
+        self._check(self._lib.pt_unpack_tiles(self._ctx, C.c_void_p(gathered_ptr), max_tiles_per_rank, C.c_void_p(frame_ptr)))
+
+    def trace_rays(self, origins, directions, tmin=0.0, use_bvh=True):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        n = len(o)
+        t = np.empty(n, dtype=np.float32)
+        ids = np.empty(n, dtype=np.uint32)
+        self._check(self._lib.pt_trace_rays(self._ctx, o.ctypes.data, d.ctypes.data, n, tmin, 1 if use_bvh else 0, t.ctypes.data, ids.ctypes.data))
+        return t, ids
+
+    def download_accel(self):
+        n = self.accel.node_count
+        nodes = np.zeros(n, dtype=BVH_NODE_DTYPE)
+        self._check(self._lib.pt_accel_download(self._ctx, nodes.ctypes.data, n))
+        order = np.zeros(self.accel.leaf_count, dtype=np.uint32)
+        self._check(self._lib.pt_accel_download_order(self._ctx, order.ctypes.data, len(order)))
+        return nodes, order

@@ -1,0 +1,608 @@
+// pt_api.hip -- implementation of the C-ABI (include/pt_api.h) on the HIP runtime: context, device
+// memory, LBVH upload, and the per-frame launch sequence of the wavefront kernel set.
+// There is no CPU fallback here by design: without a HIP device pt_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_api.h"
+#include "pt_kernels.h"
+#include "pt_lbvh.h"
+#include "pt_lbvh_gpu.h"
+
+using namespace pt;
+
+namespace {
+
+constexpr uint32_t kMaxLdsBytes = 160u * 1024u;  // gfx950 LDS per CU / per workgroup
+constexpr uint32_t kLdsSceneBudget = 64u * 1024u; // stage the BVH in LDS only while two 512-thread blocks still fit per CU
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kind;  // 0 primary, 1 traverse, 2 shade
+};
+
+}  // namespace
+
+struct PtContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t flags = 0;
+    uint32_t tile_size = 32;
+    uint32_t num_cus = 256;
+    std::string err;
+
+    // scene
+    uint32_t n = 0;
+    float4* d_sph = nullptr;
+    float4* d_mats = nullptr;
+    PtSceneData sd{};
+    std::vector<PtSphere> h_sph;
+    bool scene_set = false;
+
+    // accel
+    float4* d_nodes = nullptr;
+    float4* d_sph_sorted = nullptr;
+    uint32_t* d_sorted_id = nullptr;
+    uint32_t n_nodes = 0, depth = 0;
+    bool lds_scene = false;
+    bool accel_valid = false;
+    LbvhResult lbvh;  // host copy (download / info); filled by either builder
+    LbvhGpu* gpu_builder = nullptr;
+
+    // frame state
+    PtCamera cam{};
+    PtGraphicsSettings gs{};
+    bool cam_set = false, gs_set = false;
+    uint32_t rank = 0, world = 1;
+
+    // work buffers
+    size_t cap_slots = 0;
+    RayQueue q[2]{};
+    Scratch scratch{};
+    bool scratch_spp = false;
+    uint32_t* d_counts = nullptr;
+    size_t cap_counts = 0;
+    uint32_t* h_counts = nullptr;  // pinned
+    float4* d_out = nullptr;
+    size_t cap_out = 0;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profiling = false;
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+PtStatus fail(PtContext* ctx, PtStatus st, const std::string& msg)
+{
+    if (ctx) ctx->err = msg;
+    return st;
+}
+
+#define PT_HIP(ctx, expr)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP,                      \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                            \
+        }                                                                                              \
+    } while (0)
+
+template <typename T>
+void free_dev(T*& p)
+{
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+void free_queues(PtContext* c)
+{
+    for (auto& q : c->q) { free_dev(q.q0); free_dev(q.q1); free_dev(q.q2); free_dev(q.hit); }
+    free_dev(c->scratch.sample_rad); free_dev(c->scratch.radiance); free_dev(c->scratch.primary_hit);
+    c->cap_slots = 0;
+    c->scratch_spp = false;
+}
+
+PtStatus ensure_buffers(PtContext* c, size_t n_slots, bool need_spp, size_t n_counts)
+{
+    if (n_slots > c->cap_slots) {
+        free_queues(c);
+        for (auto& q : c->q) {
+            PT_HIP(c, hipMalloc(&q.q0, n_slots * sizeof(float4)));
+            PT_HIP(c, hipMalloc(&q.q1, n_slots * sizeof(float4)));
+            PT_HIP(c, hipMalloc(&q.q2, n_slots * sizeof(float4)));
+            PT_HIP(c, hipMalloc(&q.hit, n_slots * sizeof(uint2)));
+        }
+        PT_HIP(c, hipMalloc(&c->scratch.sample_rad, n_slots * sizeof(float4)));
+        c->cap_slots = n_slots;
+    }
+    if (need_spp && !c->scratch_spp) {
+        PT_HIP(c, hipMalloc(&c->scratch.radiance, c->cap_slots * sizeof(float4)));
+        PT_HIP(c, hipMalloc(&c->scratch.primary_hit, c->cap_slots * sizeof(uint2)));
+        c->scratch_spp = true;
+    }
+    if (n_counts > c->cap_counts) {
+        free_dev(c->d_counts);
+        if (c->h_counts) { (void)hipHostFree(c->h_counts); c->h_counts = nullptr; }
+        PT_HIP(c, hipMalloc(&c->d_counts, n_counts * sizeof(uint32_t)));
+        PT_HIP(c, hipHostMalloc(&c->h_counts, n_counts * sizeof(uint32_t)));
+        c->cap_counts = n_counts;
+    }
+    return PT_OK;
+}
+
+PtStatus validate_frame(PtContext* c)
+{
+    if (!c->scene_set) return fail(c, PT_ERR_STATE, "pt_set_scene has not been called");
+    if (!c->accel_valid) return fail(c, PT_ERR_STATE, "pt_build_accel has not been called for the current scene");
+    if (!c->cam_set) return fail(c, PT_ERR_STATE, "pt_set_camera has not been called");
+    if (!c->gs_set) return fail(c, PT_ERR_STATE, "pt_set_constants has not been called");
+    return PT_OK;
+}
+
+SceneView make_scene_view(const PtContext* c)
+{
+    SceneView sv{};
+    sv.nodes = c->d_nodes;
+    sv.sph_sorted = c->d_sph_sorted;
+    sv.sorted_id = c->d_sorted_id;
+    sv.sph = c->d_sph;
+    sv.mats = c->d_mats;
+    sv.n = c->n;
+    sv.n_nodes = c->n_nodes;
+    sv.stack_depth = std::max(1u, c->depth);
+    sv.lds_scene = c->lds_scene ? 1u : 0u;
+    for (int i = 0; i < 4; i++) sv.env[i] = c->sd.EnvironmentLightColor[i];
+    return sv;
+}
+
+FrameParams make_frame_params(const PtContext* c)
+{
+    FrameParams fp{};
+    fp.cam = camera_params(c->cam);
+    fp.frame_index = c->gs.FrameIndex;
+    fp.bounces = c->gs.Bounces;
+    fp.spp = c->gs.SamplesPerPixel;
+    fp.rr_enabled = c->gs.IsRussianRouletteEnabled ? 1u : 0u;
+    fp.throughput_threshold = c->gs.ThroughputThreshold;
+    return fp;
+}
+
+uint32_t env_u32(const char* name, uint32_t dflt)
+{
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    return (uint32_t)std::strtoul(v, nullptr, 10);
+}
+
+EventPair* next_events(PtContext* c, int kind)
+{
+    if (c->ev_used == c->ev_pool.size()) {
+        EventPair p{};
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(p);
+    }
+    EventPair* p = &c->ev_pool[c->ev_used++];
+    p->kind = kind;
+    return p;
+}
+
+// The per-frame launch sequence.  out: device float4 buffer addressed by PixelRef::out_index.
+PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, float4* out, PtStats* stats)
+{
+    const uint32_t bounces = c->gs.Bounces, spp = c->gs.SamplesPerPixel;
+    const size_t max_iters = (size_t)spp * bounces + 1;  // shade passes; traverse passes = max_iters - 1
+    PtStatus st = ensure_buffers(c, pm.n_slots, spp > 1, max_iters + 2);
+    if (st != PT_OK) return st;
+
+    const SceneView sv = make_scene_view(c);
+    const FrameParams fp = make_frame_params(c);
+    const uint32_t lds = traverse_lds_bytes_for(sv.n_nodes, sv.n, sv.stack_depth, c->lds_scene);
+    if (lds > kMaxLdsBytes) return fail(c, PT_ERR_UNSUPPORTED, "BVH depth needs more traversal-stack LDS than a workgroup can have");
+
+    const uint32_t trav_blocks = (pm.n_slots + kTraverseThreads - 1) / kTraverseThreads;
+    const uint32_t shade_blocks = (pm.n_slots + kShadeThreads - 1) / kShadeThreads;
+    const uint32_t trav_grid = std::max(1u, std::min(trav_blocks, c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", 8)));
+    const uint32_t shade_grid = std::max(1u, std::min(shade_blocks, c->num_cus * env_u32("PT_SHADE_BLOCKS_PER_CU", 16)));
+
+    const bool timed = stats != nullptr;
+    c->ev_used = 0;
+    if (timed) PT_HIP(c, hipEventRecord(c->ev0, c->stream));
+    PT_HIP(c, hipMemsetAsync(c->d_counts, 0, (max_iters + 2) * sizeof(uint32_t), c->stream));
+
+    auto bracket = [&](int kind, auto&& launch) -> hipError_t {
+        EventPair* ev = c->profiling ? next_events(c, kind) : nullptr;
+        if (ev) (void)hipEventRecord(ev->a, c->stream);
+        hipError_t e = launch();
+        if (ev) (void)hipEventRecord(ev->b, c->stream);
+        return e;
+    };
+
+    PT_HIP(c, bracket(0, [&] { return launch_primary(sv, pm, fp, c->q[0], c->scratch, out, c->d_counts, trav_grid, c->stream); }));
+
+    size_t iters_done = 0;
+    for (size_t k = 0; k < max_iters; k++) {
+        const RayQueue& qin = c->q[k & 1];
+        const RayQueue& qout = c->q[(k + 1) & 1];
+        PT_HIP(c, bracket(2, [&] { return launch_shade(sv, pm, fp, qin, qout, c->scratch, out, c->d_counts + k, c->d_counts + k + 1, shade_grid, c->stream); }));
+        iters_done = k + 1;
+        if (k + 1 == max_iters) break;
+        if (spp > 1) {
+            // sample regeneration keeps the queue alive for a data-dependent number of passes: poll its size
+            PT_HIP(c, hipMemcpyAsync(c->h_counts + k + 1, c->d_counts + k + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            PT_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->h_counts[k + 1] == 0) break;
+        }
+        PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, c->d_counts + k + 1, trav_grid, c->stream); }));
+    }
+    if (timed) {
+        PT_HIP(c, hipEventRecord(c->ev1, c->stream));
+        PT_HIP(c, hipMemcpyAsync(c->h_counts, c->d_counts, (iters_done + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+        std::memset(stats, 0, sizeof *stats);
+        float ms = 0;
+        PT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        stats->ms_total = ms;
+        uint64_t secondary = 0;
+        for (size_t k = 1; k <= iters_done; k++) secondary += c->h_counts[k];
+        stats->rays = valid_pixels + secondary;
+        stats->pixels = valid_pixels;
+        stats->paths = valid_pixels * spp;
+        // DESIGN.md byte model: secondary ray = 48 (shade write) + 32 + 8 (traverse) + 56 (shade read);
+        // primary slot = 56 (primary write) + 56 (shade read); pixel = 16 (final store);
+        // spp > 1 adds the radiance read-modify-write (32) per sample and the primary-hit cache (8 + 8).
+        stats->bytes_algorithmic = 144ull * secondary + 112ull * pm.n_slots + 16ull * valid_pixels
+                                   + (spp > 1 ? 48ull * valid_pixels * spp : 0ull);
+        if (c->profiling) {
+            for (size_t i = 0; i < c->ev_used; i++) {
+                float t = 0;
+                if (hipEventElapsedTime(&t, c->ev_pool[i].a, c->ev_pool[i].b) != hipSuccess) continue;
+                if (c->ev_pool[i].kind == 2) { stats->ms_shade += t; stats->shade_launches++; }
+                else { stats->ms_traverse += t; stats->traverse_launches++; }  // primary counts as a traverse launch
+            }
+        }
+    }
+    return PT_OK;
+}
+
+uint64_t count_tile_pixels(uint32_t w, uint32_t h, uint32_t ts, uint32_t rank, uint32_t world)
+{
+    const uint32_t tx = (w + ts - 1) / ts, ty = (h + ts - 1) / ts, total = tx * ty;
+    uint64_t px = 0;
+    for (uint32_t t = rank; t < total; t += world) {
+        const uint32_t x0 = (t % tx) * ts, y0 = (t / tx) * ts;
+        px += (uint64_t)std::min(ts, w - x0) * std::min(ts, h - y0);
+    }
+    return px;
+}
+
+}  // namespace
+
+// ==================================================================================================== C-ABI
+extern "C" {
+
+const char* pt_version(void) { return "dxrs-amd 0.1 (gfx950)"; }
+
+PtStatus pt_create(const PtConfig* config, PtContext** out_ctx)
+{
+    if (!config || !out_ctx) return PT_ERR_INVALID_ARG;
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return PT_ERR_NO_DEVICE;
+    if (config->device < 0 || config->device >= count) return PT_ERR_INVALID_ARG;
+    PtContext* c = new (std::nothrow) PtContext();
+    if (!c) return PT_ERR_OOM;
+    c->device = config->device;
+    c->flags = config->flags;
+    c->tile_size = config->tile_size ? config->tile_size : 32;
+    if (c->tile_size % 8 != 0 || c->tile_size > 1024) { delete c; return PT_ERR_INVALID_ARG; }
+    if (hipSetDevice(c->device) != hipSuccess) { delete c; return PT_ERR_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = (uint32_t)prop.multiProcessorCount;
+    if (config->stream) {
+        c->stream = reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(config->stream));
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERR_HIP; }
+        c->own_stream = true;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
+    *out_ctx = c;
+    return PT_OK;
+}
+
+void pt_destroy(PtContext* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_queues(c);
+    free_dev(c->d_sph); free_dev(c->d_mats); free_dev(c->d_nodes); free_dev(c->d_sph_sorted); free_dev(c->d_sorted_id);
+    free_dev(c->d_counts); free_dev(c->d_out);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->gpu_builder) lbvh_gpu_destroy(c->gpu_builder);
+    for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* pt_last_error(PtContext* c) { return c ? c->err.c_str() : "null context"; }
+
+PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* materials, uint32_t n, const PtSceneData* sd)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!spheres || !materials || !sd || n == 0) return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: null pointer or n == 0");
+    if (n > (1u << 30)) return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: too many spheres");
+    if (sd->EnvironmentLightTextureDescriptor != ~0u)
+        return fail(c, PT_ERR_UNSUPPORTED, "environment light textures are not supported (EnvironmentLightTextureDescriptor must be ~0u)");
+    for (uint32_t i = 0; i < n; i++)
+        if (!(spheres[i].r > 0.0f) || !std::isfinite(spheres[i].r) || !std::isfinite(spheres[i].cx) || !std::isfinite(spheres[i].cy) || !std::isfinite(spheres[i].cz))
+            return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: sphere " + std::to_string(i) + " has a non-finite centre or non-positive radius");
+    PT_HIP(c, hipSetDevice(c->device));
+    if (n != c->n) {
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+        free_dev(c->d_sph); free_dev(c->d_mats);
+        PT_HIP(c, hipMalloc(&c->d_sph, (size_t)n * sizeof(float4)));
+        PT_HIP(c, hipMalloc(&c->d_mats, (size_t)n * sizeof(PtMaterial)));
+    }
+    c->n = n;
+    c->h_sph.assign(spheres, spheres + n);
+    PT_HIP(c, hipMemcpyAsync(c->d_sph, spheres, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    PT_HIP(c, hipMemcpyAsync(c->d_mats, materials, (size_t)n * sizeof(PtMaterial), hipMemcpyHostToDevice, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));  // caller-owned host memory may be released on return
+    c->sd = *sd;
+    c->scene_set = true;
+    c->accel_valid = false;
+    return PT_OK;
+}
+
+PtStatus pt_build_accel(PtContext* c, PtAccelInfo* info)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!c->scene_set) return fail(c, PT_ERR_STATE, "pt_build_accel: no scene");
+    PT_HIP(c, hipSetDevice(c->device));
+    const uint32_t n = c->n;
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->n_nodes != (n > 1 ? n - 1 : 0) || !c->d_sph_sorted) {
+        free_dev(c->d_nodes); free_dev(c->d_sph_sorted); free_dev(c->d_sorted_id);
+        PT_HIP(c, hipMalloc(&c->d_nodes, (size_t)std::max(1u, n - 1) * sizeof(PtBvhNode)));
+        PT_HIP(c, hipMalloc(&c->d_sph_sorted, (size_t)n * sizeof(float4)));
+        PT_HIP(c, hipMalloc(&c->d_sorted_id, (size_t)n * sizeof(uint32_t)));
+    }
+    c->n_nodes = n > 1 ? n - 1 : 0;
+    float build_ms = 0;
+    if ((c->flags & PT_FLAG_HOST_LBVH) || !lbvh_gpu_available()) {
+        auto t0 = std::chrono::steady_clock::now();
+        build_lbvh_host(c->h_sph.data(), n, c->lbvh);
+        auto t1 = std::chrono::steady_clock::now();
+        build_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+        if (c->n_nodes) PT_HIP(c, hipMemcpyAsync(c->d_nodes, c->lbvh.nodes.data(), (size_t)c->n_nodes * sizeof(PtBvhNode), hipMemcpyHostToDevice, c->stream));
+        PT_HIP(c, hipMemcpyAsync(c->d_sph_sorted, c->lbvh.sorted.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+        PT_HIP(c, hipMemcpyAsync(c->d_sorted_id, c->lbvh.sorted_id.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+        c->depth = c->lbvh.depth;
+    } else {
+        if (!c->gpu_builder) {
+            c->gpu_builder = lbvh_gpu_create();
+            if (!c->gpu_builder) return fail(c, PT_ERR_OOM, "pt_build_accel: cannot create the device LBVH builder");
+        }
+        LbvhGpuInfo gi{};
+        hipError_t e = lbvh_gpu_build(c->gpu_builder, c->d_sph, n, reinterpret_cast<PtBvhNode*>(c->d_nodes), c->d_sph_sorted, c->d_sorted_id, c->stream, &gi);
+        if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP, std::string("device LBVH build: ") + hipGetErrorString(e));
+        c->depth = gi.depth;
+        build_ms = gi.build_ms;
+        c->lbvh = LbvhResult{};
+        c->lbvh.depth = gi.depth;
+        c->lbvh.pad = gi.pad;
+        for (int a = 0; a < 3; a++) { c->lbvh.bounds_min[a] = gi.bounds_min[a]; c->lbvh.bounds_max[a] = gi.bounds_max[a]; }
+    }
+    // stage the BVH in LDS when scene + stacks leave room for two workgroups per CU
+    const uint32_t scene_bytes = traverse_lds_bytes_for(c->n_nodes, n, 0, true);
+    c->lds_scene = !(c->flags & PT_FLAG_NO_LDS_SCENE) && scene_bytes <= kLdsSceneBudget
+                   && traverse_lds_bytes_for(c->n_nodes, n, std::max(1u, c->depth), true) <= kMaxLdsBytes / 2;
+    c->accel_valid = true;
+    if (info) {
+        std::memset(info, 0, sizeof *info);
+        info->leaf_count = n;
+        info->node_count = c->n_nodes;
+        info->depth = c->depth;
+        info->lds_resident = c->lds_scene ? 1u : 0u;
+        for (int a = 0; a < 3; a++) { info->bounds_min[a] = c->lbvh.bounds_min[a]; info->bounds_max[a] = c->lbvh.bounds_max[a]; }
+        info->build_ms = build_ms;
+    }
+    return PT_OK;
+}
+
+PtStatus pt_set_camera(PtContext* c, const PtCamera* camera)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!camera) return fail(c, PT_ERR_INVALID_ARG, "pt_set_camera: null camera");
+    c->cam = *camera;
+    c->cam_set = true;
+    return PT_OK;
+}
+
+PtStatus pt_set_constants(PtContext* c, const PtGraphicsSettings* gs)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!gs) return fail(c, PT_ERR_INVALID_ARG, "pt_set_constants: null settings");
+    if (gs->RenderSize[0] == 0 || gs->RenderSize[1] == 0 || gs->RenderSize[0] > 65535u || gs->RenderSize[1] > 65535u)
+        return fail(c, PT_ERR_INVALID_ARG, "pt_set_constants: RenderSize must be in [1, 65535]^2 (the RNG seed packs (x << 16) | y)");
+    if (gs->SamplesPerPixel == 0 || gs->SamplesPerPixel > 65535u) return fail(c, PT_ERR_INVALID_ARG, "pt_set_constants: SamplesPerPixel must be in [1, 65535]");
+    if (gs->Bounces > 250u) return fail(c, PT_ERR_INVALID_ARG, "pt_set_constants: Bounces must be <= 250");
+    if (gs->IsDIEnabled) return fail(c, PT_ERR_UNSUPPORTED, "IsDIEnabled must be 0 (ReSTIR-DI is out of scope)");
+    if (gs->Denoiser) return fail(c, PT_ERR_UNSUPPORTED, "Denoiser must be 0 == Denoiser::None");
+    c->gs = *gs;
+    c->gs_set = true;
+    return PT_OK;
+}
+
+PtStatus pt_set_partition(PtContext* c, uint32_t rank, uint32_t world)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (world == 0 || rank >= world) return fail(c, PT_ERR_INVALID_ARG, "pt_set_partition: need rank < world");
+    c->rank = rank;
+    c->world = world;
+    return PT_OK;
+}
+
+uint32_t pt_tiles_count(PtContext* c, uint32_t rank)
+{
+    if (!c || !c->gs_set || rank >= c->world) return 0;
+    const uint32_t ts = c->tile_size;
+    const uint32_t total = ((c->gs.RenderSize[0] + ts - 1) / ts) * ((c->gs.RenderSize[1] + ts - 1) / ts);
+    return rank < total ? (total - rank + c->world - 1) / c->world : 0;
+}
+
+PtStatus pt_render(PtContext* c, const PtRect* rect, void* out, int out_is_device, PtStats* stats)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!out) return fail(c, PT_ERR_INVALID_ARG, "pt_render: null output");
+    PtStatus st = validate_frame(c);
+    if (st != PT_OK) return st;
+    PT_HIP(c, hipSetDevice(c->device));
+    PtRect r = rect ? *rect : PtRect{ 0, 0, c->gs.RenderSize[0], c->gs.RenderSize[1] };
+    if (r.w == 0 || r.h == 0 || r.x + r.w > c->gs.RenderSize[0] || r.y + r.h > c->gs.RenderSize[1])
+        return fail(c, PT_ERR_INVALID_ARG, "pt_render: rect is empty or outside RenderSize");
+    PixelMap pm{};
+    pm.mode = 0;
+    pm.img_w = c->gs.RenderSize[0]; pm.img_h = c->gs.RenderSize[1];
+    pm.rx = r.x; pm.ry = r.y; pm.rw = r.w; pm.rh = r.h;
+    pm.blocks_x = (r.w + 7) / 8;
+    const uint64_t slots = (uint64_t)pm.blocks_x * ((r.h + 7) / 8) * 64ull;
+    if (slots > 0xFFFFFFFFull) return fail(c, PT_ERR_INVALID_ARG, "pt_render: rect too large");
+    pm.n_slots = (uint32_t)slots;
+    float4* dev_out = static_cast<float4*>(out);
+    const size_t out_px = (size_t)r.w * r.h;
+    if (!out_is_device) {
+        if (out_px > c->cap_out) {
+            PT_HIP(c, hipStreamSynchronize(c->stream));
+            free_dev(c->d_out);
+            PT_HIP(c, hipMalloc(&c->d_out, out_px * sizeof(float4)));
+            c->cap_out = out_px;
+        }
+        dev_out = c->d_out;
+    }
+    st = render_common(c, pm, (uint64_t)r.w * r.h, dev_out, stats);
+    if (st != PT_OK) return st;
+    if (!out_is_device) {
+        PT_HIP(c, hipMemcpyAsync(out, dev_out, out_px * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return PT_OK;
+}
+
+PtStatus pt_render_tiles(PtContext* c, void* out_device_packed, PtStats* stats)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!out_device_packed) return fail(c, PT_ERR_INVALID_ARG, "pt_render_tiles: null output");
+    PtStatus st = validate_frame(c);
+    if (st != PT_OK) return st;
+    PT_HIP(c, hipSetDevice(c->device));
+    const uint32_t ts = c->tile_size, w = c->gs.RenderSize[0], h = c->gs.RenderSize[1];
+    PixelMap pm{};
+    pm.mode = 1;
+    pm.img_w = w; pm.img_h = h;
+    pm.ts = ts;
+    pm.tiles_x = (w + ts - 1) / ts;
+    pm.tiles_total = pm.tiles_x * ((h + ts - 1) / ts);
+    pm.rank = c->rank; pm.world = c->world;
+    const uint64_t slots = (uint64_t)pt_tiles_count(c, c->rank) * ts * ts;
+    if (slots == 0) return PT_OK;
+    if (slots > 0xFFFFFFFFull) return fail(c, PT_ERR_INVALID_ARG, "pt_render_tiles: too many pixels");
+    pm.n_slots = (uint32_t)slots;
+    return render_common(c, pm, count_tile_pixels(w, h, ts, c->rank, c->world), static_cast<float4*>(out_device_packed), stats);
+}
+
+PtStatus pt_unpack_tiles(PtContext* c, const void* gathered, uint32_t max_tiles_per_rank, void* frame)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!gathered || !frame || !c->gs_set) return fail(c, PT_ERR_INVALID_ARG, "pt_unpack_tiles: null pointer or no constants");
+    if (max_tiles_per_rank < pt_tiles_count(c, 0)) return fail(c, PT_ERR_INVALID_ARG, "pt_unpack_tiles: max_tiles_per_rank too small");
+    PT_HIP(c, hipSetDevice(c->device));
+    const uint32_t ts = c->tile_size, w = c->gs.RenderSize[0], h = c->gs.RenderSize[1];
+    PT_HIP(c, launch_unpack_tiles(static_cast<const float4*>(gathered), static_cast<float4*>(frame), w, h, ts, (w + ts - 1) / ts, c->world,
+                                  max_tiles_per_rank, c->stream));
+    return PT_OK;
+}
+
+PtStatus pt_trace_rays(PtContext* c, const float* origins, const float* directions, uint32_t n, float tmin, int use_bvh, float* out_t, uint32_t* out_id)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!origins || !directions || !out_t || !out_id) return fail(c, PT_ERR_INVALID_ARG, "pt_trace_rays: null pointer");
+    if (!c->scene_set || !c->accel_valid) return fail(c, PT_ERR_STATE, "pt_trace_rays: scene / accel not ready");
+    if (n == 0) return PT_OK;
+    PT_HIP(c, hipSetDevice(c->device));
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
+    uint32_t* d_id = nullptr;
+    PtStatus st = PT_OK;
+    auto cleanup = [&] { free_dev(d_o); free_dev(d_d); free_dev(d_t); free_dev(d_id); };
+    hipError_t e;
+    if ((e = hipMalloc(&d_o, (size_t)n * 12)) != hipSuccess || (e = hipMalloc(&d_d, (size_t)n * 12)) != hipSuccess
+        || (e = hipMalloc(&d_t, (size_t)n * 4)) != hipSuccess || (e = hipMalloc(&d_id, (size_t)n * 4)) != hipSuccess) {
+        cleanup();
+        return fail(c, PT_ERR_OOM, std::string("pt_trace_rays: ") + hipGetErrorString(e));
+    }
+    const SceneView sv = make_scene_view(c);
+    if ((e = hipMemcpyAsync(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice, c->stream)) != hipSuccess
+        || (e = hipMemcpyAsync(d_d, directions, (size_t)n * 12, hipMemcpyHostToDevice, c->stream)) != hipSuccess
+        || (e = launch_trace(sv, d_o, d_d, n, tmin, use_bvh, d_t, d_id, c->stream)) != hipSuccess
+        || (e = hipMemcpyAsync(out_t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess
+        || (e = hipMemcpyAsync(out_id, d_id, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess
+        || (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+        st = fail(c, PT_ERR_HIP, std::string("pt_trace_rays: ") + hipGetErrorString(e));
+    }
+    cleanup();
+    return st;
+}
+
+PtStatus pt_accel_download(PtContext* c, PtBvhNode* nodes, uint32_t capacity)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!c->accel_valid) return fail(c, PT_ERR_STATE, "pt_accel_download: no accel");
+    if (!nodes || capacity < c->n_nodes) return fail(c, PT_ERR_INVALID_ARG, "pt_accel_download: buffer too small");
+    if (c->n_nodes == 0) return PT_OK;
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipMemcpyAsync(nodes, c->d_nodes, (size_t)c->n_nodes * sizeof(PtBvhNode), hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+PtStatus pt_accel_download_order(PtContext* c, uint32_t* sorted_id, uint32_t capacity)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!c->accel_valid) return fail(c, PT_ERR_STATE, "pt_accel_download_order: no accel");
+    if (!sorted_id || capacity < c->n) return fail(c, PT_ERR_INVALID_ARG, "pt_accel_download_order: buffer too small");
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipMemcpyAsync(sorted_id, c->d_sorted_id, (size_t)c->n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+PtStatus pt_set_profiling(PtContext* c, int enabled)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    c->profiling = enabled != 0;
+    return PT_OK;
+}
+
+PtStatus pt_synchronize(PtContext* c)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+}  // extern "C"

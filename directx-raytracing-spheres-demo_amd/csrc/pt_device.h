@@ -1,0 +1,106 @@
+// pt_device.h -- device-side data layout shared by the kernels (pt_kernels.hip) and the C-ABI
+// implementation (pt_api.hip).  See DESIGN.md "Data layout in HBM".
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_bsdf.h"
+
+namespace pt {
+
+// ---- ray queue: SoA of three float4 streams (48 B per ray) + one 8-B hit stream --------------------
+//   q0[i] = { o.x, o.y, o.z, bits(slot) }        slot = path slot (-> pixel, scratch index)
+//   q1[i] = { d.x, d.y, d.z, bits(rng state) }
+//   q2[i] = { T.r, T.g, T.b, bits(flags) }       flags = bounce | sample << 8 | srad_dirty << 24
+//   hit[i] = { bits(t), sphere id (0xFFFFFFFF = miss) }
+struct RayQueue {
+    float4* q0;
+    float4* q1;
+    float4* q2;
+    uint2* hit;
+};
+
+constexpr uint32_t kFlagBounceMask = 0xFFu;
+constexpr uint32_t kFlagSampleShift = 8;
+constexpr uint32_t kFlagSampleMask = 0xFFFFu;
+constexpr uint32_t kFlagDirty = 1u << 24;
+constexpr uint32_t kMissId = 0xFFFFFFFFu;
+
+// ---- scene view ------------------------------------------------------------------------------------
+// BVH node = 64 B = 4 float4 (PtBvhNode of include/pt_api.h):
+//   n0 = lo0.xyz, hi0.x   n1 = hi0.yz, lo1.xy   n2 = lo1.z, hi1.xyz   n3 = child0, child1, parent, pad (ints)
+struct SceneView {
+    const float4* nodes;        // n_nodes * 4
+    const float4* sph_sorted;   // Morton order {cx,cy,cz,r}
+    const uint32_t* sorted_id;  // Morton order -> original sphere id
+    const float4* sph;          // original order (shade)
+    const float4* mats;         // original order, PtMaterial as 4 float4
+    uint32_t n;                 // spheres
+    uint32_t n_nodes;           // internal nodes (n - 1; 0 when n == 1)
+    uint32_t stack_depth;       // traversal stack entries per lane
+    uint32_t lds_scene;         // 1: kernels stage nodes + sph_sorted + sorted_id in LDS
+    float env[4];               // SceneData.EnvironmentLightColor
+};
+
+// ---- slot -> pixel mapping ---------------------------------------------------------------------------
+// A slot is 64-aligned to an 8x8 pixel block so that one wave64 = one 8x8 block of pixels.
+//   mode 0 (rect):  block b = slot / 64 over ceil(w/8) x ceil(h/8) blocks of the rect
+//   mode 1 (tiles): tile k = slot / ts^2 is this rank's k-th tile = global tile (rank + k * world)
+struct PixelMap {
+    uint32_t mode;
+    uint32_t img_w, img_h;        // RenderSize
+    uint32_t rx, ry, rw, rh;      // rect (mode 0)
+    uint32_t blocks_x;            // ceil(rw / 8) (mode 0)
+    uint32_t ts, tiles_x, tiles_total, rank, world;  // mode 1
+    uint32_t n_slots;
+};
+
+struct PixelRef {
+    uint32_t px, py;     // global pixel
+    uint32_t out_index;  // index into the output float4 buffer
+    bool valid;
+};
+
+__device__ __forceinline__ PixelRef slot_to_pixel(const PixelMap& m, uint32_t slot)
+{
+    PixelRef r;
+    if (m.mode == 0) {
+        uint32_t b = slot >> 6, l = slot & 63u;
+        uint32_t bx = b % m.blocks_x, by = b / m.blocks_x;
+        uint32_t x = bx * 8u + (l & 7u), y = by * 8u + (l >> 3);
+        r.valid = x < m.rw && y < m.rh;
+        r.px = m.rx + x;
+        r.py = m.ry + y;
+        r.out_index = y * m.rw + x;
+    } else {
+        uint32_t ts2 = m.ts * m.ts;
+        uint32_t k = slot / ts2, w = slot - k * ts2;
+        // 8x8 blocks inside the tile so a wave stays coherent
+        uint32_t bpt = m.ts >> 3;  // blocks per tile row
+        uint32_t b = w >> 6, l = w & 63u;
+        uint32_t lx = (b % bpt) * 8u + (l & 7u), ly = (b / bpt) * 8u + (l >> 3);
+        uint32_t gt = m.rank + k * m.world;
+        uint32_t tx = gt % m.tiles_x, ty = gt / m.tiles_x;
+        r.px = tx * m.ts + lx;
+        r.py = ty * m.ts + ly;
+        r.valid = gt < m.tiles_total && r.px < m.img_w && r.py < m.img_h;
+        r.out_index = k * ts2 + ly * m.ts + lx;
+    }
+    return r;
+}
+
+struct FrameParams {
+    CameraParams cam;
+    uint32_t frame_index, bounces, spp, rr_enabled;
+    float throughput_threshold;
+};
+
+// per-slot scratch (only touched when needed, see shade kernel)
+struct Scratch {
+    float4* sample_rad;   // sampleRadiance of the sample in flight (valid when kFlagDirty)
+    float4* radiance;     // sum over finished samples (spp > 1)
+    uint2* primary_hit;   // cached primary hit for sample regeneration (spp > 1)
+};
+
+}  // namespace pt

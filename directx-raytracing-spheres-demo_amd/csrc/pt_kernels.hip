@@ -1,0 +1,491 @@
+// pt_kernels.hip -- the wavefront kernel set of the bounce loop for gfx950 (wave64).
+//
+//   primary_kernel   ray generation (Camera.hlsli:27-41, Raytracing.hlsl:106-138) + primary closest hit
+//                    (GBufferGeneration.hlsl:125-129) -> ray queue 0 + hit stream
+//   traverse_kernel  closest hit of every queued ray against the LBVH (replaces CastRay /
+//                    RayQuery traversal, RaytracingHelpers.hlsli:57-133) -> hit stream
+//   shade_kernel     one bounce of Raytracing.hlsl:213-364: environment / emission accumulate, material ->
+//                    BSDFSample, lobe select + sample, PDF, BSDF, Russian roulette, throughput cutoff, sample
+//                    regeneration; wave64 ballot + prefix compaction of the surviving rays into the next queue
+//   trace_kernel / brute_kernel   test hooks (pt_trace_rays)
+//
+// Everything is compiled with -ffp-contract=off; arithmetic that decides a branch follows pt_math.h /
+// pt_bsdf.h (bit-exact with the CPU oracle).  The AABB slab test is traversal-only arithmetic: it must be
+// conservative, not bit-reproducible on the CPU (DESIGN.md "LBVH").
+#include "pt_kernels.h"
+
+namespace pt {
+
+// ------------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// Stage the BVH (nodes, Morton-ordered spheres, ids) into LDS.  Layout: [nodes | spheres | ids].
+__device__ __forceinline__ void stage_scene(const SceneView& sv, float4* lds)
+{
+    const uint32_t n_vec = sv.n_nodes * 4u + sv.n;
+    for (uint32_t i = threadIdx.x; i < n_vec; i += blockDim.x)
+        lds[i] = i < sv.n_nodes * 4u ? sv.nodes[i] : sv.sph_sorted[i - sv.n_nodes * 4u];
+    uint32_t* ids = reinterpret_cast<uint32_t*>(lds + n_vec);
+    for (uint32_t i = threadIdx.x; i < sv.n; i += blockDim.x) ids[i] = sv.sorted_id[i];
+    __syncthreads();
+}
+
+__host__ __device__ inline uint32_t scene_lds_bytes(uint32_t n_nodes, uint32_t n) { return (n_nodes * 4u + n) * 16u + ((n * 4u + 15u) & ~15u); }
+
+// Closest hit over the LBVH.  nodes/sph/ids may live in LDS or global memory (address space is inferred after
+// inlining).  stack: per-lane stack, entry e of lane l at stack[e * stride + l].
+// Result is identical to brute force: nearest t, ties -> lowest original id (boxes are padded, culling is <=).
+template <typename StackT>
+__device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, const float4* __restrict__ sph,
+                                            const uint32_t* __restrict__ ids, uint32_t n, f3 o, f3 d, float tmin, float tmax,
+                                            StackT* stack, uint32_t stride, float& t_out, uint32_t& id_out)
+{
+    float best = tmax;
+    uint32_t best_id = kMissId;
+    if (n == 1) {
+        float4 s = sph[0];
+        float t;
+        if (intersect_sphere(o, d, tmin, best, make_f3(s.x, s.y, s.z), s.w, t)) { best = t; best_id = ids[0]; }
+        t_out = best; id_out = best_id;
+        return;
+    }
+    const float ix = fast_rcp(d.x), iy = fast_rcp(d.y), iz = fast_rcp(d.z);
+    const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
+    int node = 0;
+    uint32_t sp = 0;
+    for (;;) {
+        const float4 n0 = nodes[node * 4 + 0];
+        const float4 n1 = nodes[node * 4 + 1];
+        const float4 n2 = nodes[node * 4 + 2];
+        const float4 n3 = nodes[node * 4 + 3];
+        // child 0: lo = (n0.x,n0.y,n0.z) hi = (n0.w,n1.x,n1.y); child 1: lo = (n1.z,n1.w,n2.x) hi = (n2.y,n2.z,n2.w)
+        float ax = pt_fma(n0.x, ix, ox), bx = pt_fma(n0.w, ix, ox);
+        float ay = pt_fma(n0.y, iy, oy), by = pt_fma(n1.x, iy, oy);
+        float az = pt_fma(n0.z, iz, oz), bz = pt_fma(n1.y, iz, oz);
+        float tn0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+        float tf0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
+        ax = pt_fma(n1.z, ix, ox); bx = pt_fma(n2.y, ix, ox);
+        ay = pt_fma(n1.w, iy, oy); by = pt_fma(n2.z, iy, oy);
+        az = pt_fma(n2.x, iz, oz); bz = pt_fma(n2.w, iz, oz);
+        float tn1 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+        float tf1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
+        bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+        const int c0 = __builtin_bit_cast(int, n3.x), c1 = __builtin_bit_cast(int, n3.y);
+        if (h0 && c0 < 0) {
+            const uint32_t k = ~(uint32_t)c0;
+            const float4 s = sph[k];
+            float t;
+            if (intersect_sphere(o, d, tmin, kInf, make_f3(s.x, s.y, s.z), s.w, t)) {
+                const uint32_t id = ids[k];
+                if (t < best || (t == best && best_id != kMissId && id < best_id)) { best = t; best_id = id; }
+            }
+            h0 = false;
+        }
+        if (h1 && c1 < 0) {
+            const uint32_t k = ~(uint32_t)c1;
+            const float4 s = sph[k];
+            float t;
+            if (intersect_sphere(o, d, tmin, kInf, make_f3(s.x, s.y, s.z), s.w, t)) {
+                const uint32_t id = ids[k];
+                if (t < best || (t == best && best_id != kMissId && id < best_id)) { best = t; best_id = id; }
+            }
+            h1 = false;
+        }
+        if (h0 && h1) {
+            const bool swap = tn1 < tn0;
+            const int near_c = swap ? c1 : c0, far_c = swap ? c0 : c1;
+            stack[sp * stride] = (StackT)far_c;
+            sp++;
+            node = near_c;
+        } else if (h0) {
+            node = c0;
+        } else if (h1) {
+            node = c1;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            node = (int)stack[sp * stride];
+        }
+    }
+    // t < tmax is required by intersect_sphere's contract: best starts at tmax and only shrinks
+    t_out = best; id_out = best_id;
+}
+
+// ------------------------------------------------------------------------------------------------ primary
+template <bool kLds, typename StackT>
+__global__ __launch_bounds__(kTraverseThreads) void primary_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue q,
+                                                                   Scratch scratch, float4* __restrict__ out, uint32_t* __restrict__ count0)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count0 = pm.n_slots;  // queue 0 holds every slot
+    extern __shared__ float4 smem[];
+    const float4* nodes = sv.nodes;
+    const float4* sph = sv.sph_sorted;
+    const uint32_t* ids = sv.sorted_id;
+    StackT* stack;
+    if (kLds) {
+        stage_scene(sv, smem);
+        nodes = smem;
+        sph = smem + sv.n_nodes * 4u;
+        ids = reinterpret_cast<const uint32_t*>(smem + sv.n_nodes * 4u + sv.n);
+        stack = reinterpret_cast<StackT*>(reinterpret_cast<char*>(smem) + scene_lds_bytes(sv.n_nodes, sv.n));
+    } else {
+        stack = reinterpret_cast<StackT*>(smem);
+    }
+    stack += threadIdx.x;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < pm.n_slots; slot += gridDim.x * blockDim.x) {
+        const PixelRef pr = slot_to_pixel(pm, slot);
+        f3 o = make_f3(0, 0, 0), d = make_f3(0, 0, 1);
+        float t = kInf;
+        uint32_t id = kMissId;
+        uint32_t rng = 0;
+        if (pr.valid) {
+            float tmin, tmax;
+            primary_ray(fp.cam, pr.px, pr.py, pm.img_w, pm.img_h, o, d, tmin, tmax);
+            rng = rng_init(pr.px, pr.py, fp.frame_index);
+            closest_hit<StackT>(nodes, sph, ids, sv.n, o, d, tmin, tmax, stack, blockDim.x, t, id);
+        } else if (pm.mode == 1) {
+            // padding pixel of an edge tile (or a tile past the end): defined as zero
+            // (out_index is always inside the packed buffer in tile mode)
+            out[pr.out_index] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // invalid slots are queued as "dead": shade drops them (flags bounce = 0xFF)
+        q.q0[slot] = make_float4(o.x, o.y, o.z, as_float(slot));
+        q.q1[slot] = make_float4(d.x, d.y, d.z, as_float(rng));
+        q.q2[slot] = make_float4(1.f, 1.f, 1.f, as_float(pr.valid ? 0u : 0xFFu));
+        q.hit[slot] = make_uint2(as_uint(t), id);
+        if (fp.spp > 1) scratch.primary_hit[slot] = make_uint2(as_uint(t), id);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ traverse
+template <bool kLds, typename StackT>
+__global__ __launch_bounds__(kTraverseThreads) void traverse_kernel(SceneView sv, RayQueue q, const uint32_t* __restrict__ count_ptr)
+{
+    extern __shared__ float4 smem[];
+    const float4* nodes = sv.nodes;
+    const float4* sph = sv.sph_sorted;
+    const uint32_t* ids = sv.sorted_id;
+    StackT* stack;
+    const uint32_t count = *count_ptr;
+    if (blockIdx.x * blockDim.x >= count) return;
+    if (kLds) {
+        stage_scene(sv, smem);
+        nodes = smem;
+        sph = smem + sv.n_nodes * 4u;
+        ids = reinterpret_cast<const uint32_t*>(smem + sv.n_nodes * 4u + sv.n);
+        stack = reinterpret_cast<StackT*>(reinterpret_cast<char*>(smem) + scene_lds_bytes(sv.n_nodes, sv.n));
+    } else {
+        stack = reinterpret_cast<StackT*>(smem);
+    }
+    stack += threadIdx.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const float4 a = q.q0[i];
+        const float4 b = q.q1[i];
+        float t;
+        uint32_t id;
+        closest_hit<StackT>(nodes, sph, ids, sv.n, make_f3(a.x, a.y, a.z), make_f3(b.x, b.y, b.z), 0.0f, kInf, stack, blockDim.x, t, id);
+        q.hit[i] = make_uint2(as_uint(t), id);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ shade
+__device__ __forceinline__ f3 load3(const float4& v) { return make_f3(v.x, v.y, v.z); }
+
+__global__ __launch_bounds__(kShadeThreads) void shade_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue qin, RayQueue qout,
+                                                              Scratch scratch, float4* __restrict__ out,
+                                                              const uint32_t* __restrict__ count_in_ptr, uint32_t* __restrict__ count_out_ptr)
+{
+    __shared__ uint32_t s_wave_count[kShadeThreads / 64];
+    __shared__ uint32_t s_block_base;
+    const uint32_t count = *count_in_ptr;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        bool emit = false;
+        f3 o, d, T;
+        uint32_t slot = 0, rng = 0, flags = 0;
+        if (i < count) {
+            const float4 a = qin.q0[i], b = qin.q1[i], c = qin.q2[i];
+            const uint2 h = qin.hit[i];
+            o = load3(a); d = load3(b); T = load3(c);
+            slot = as_uint(a.w); rng = as_uint(b.w); flags = as_uint(c.w);
+            float t = as_float(h.x);
+            uint32_t id = h.y;
+            uint32_t bounce = flags & kFlagBounceMask;
+            uint32_t sample = (flags >> kFlagSampleShift) & kFlagSampleMask;
+            bool dirty = (flags & kFlagDirty) != 0;
+            if (bounce != 0xFFu) {
+                const PixelRef pr = slot_to_pixel(pm, slot);
+                for (;;) {
+                    // ---- one iteration of the bounce loop body, Raytracing.hlsl:213-364
+                    f3 srad = make_f3(0.f, 0.f, 0.f);  // sampleRadiance so far is (dirty ? scratch : 0); srad_loaded says whether `srad` holds it
+                    bool srad_loaded = false, srad_changed = false;
+                    bool end_sample = false;
+                    f3 L = make_f3(0.f, 0.f, 0.f);
+                    HitFrame hf;
+                    if (id == kMissId) {
+                        const f3 env = environment_color(sv.env[0], sv.env[1], sv.env[2], sv.env[3], d);
+                        if (bounce == 0) {  // primary miss: pixel = environment (GBufferGeneration.hlsl:223-227; Raytracing.hlsl:249-252)
+                            out[pr.out_index] = make_float4(env.x, env.y, env.z, 1.0f);
+                            break;
+                        }
+                        if (dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
+                        srad_loaded = true;
+                        srad = srad + T * env;  // :254
+                        end_sample = true;
+                    } else {
+                        const float4 sp = sv.sph[id];
+                        const float4 m0 = sv.mats[id * 4 + 0], m1 = sv.mats[id * 4 + 1], m2 = sv.mats[id * 4 + 2];
+                        hf = hit_frame(o, d, t, load3(sp), sp.w);
+                        const f3 emission = make_f3(m1.y, m1.z, m1.w) * m1.x;  // Material::GetEmission
+                        // bounce 0 mirrors the G-buffer round trip: Transmission = Metallic < 1 ? Transmission : 0 (Raytracing.hlsl:148)
+                        const float transmission = (bounce == 0 && !(m2.x < 1.0f)) ? 0.0f : m2.w;
+                        const Bsdf bsdf = bsdf_init(load3(m0), m2.x, m2.y, m2.z, transmission, hf.front);
+                        const bool t_finite = is_finite(T.x) && is_finite(T.y) && is_finite(T.z);
+                        if (emission.x != 0.0f || emission.y != 0.0f || emission.z != 0.0f || !t_finite) {
+                            if (dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
+                            srad_loaded = true;
+                            srad = srad + T * emission;  // :320
+                            srad_changed = true;
+                        }
+                        const bool last = bounce == fp.bounces;
+                        if (last && sample + 1 == fp.spp) {
+                            end_sample = true;  // the sample drawn on the final iteration is never used and no later sample reads the RNG
+                        } else {
+                            const f3 Ns = hf.front ? hf.N : -hf.N;  // HitInfo.hlsli:60-64
+                            const Surf surf = surf_init(hf.front, hf.N, Ns);
+                            const f3 V = -d;
+                            float w[3];
+                            lobe_weights(bsdf, surf, V, w);
+                            float rnd[4];
+                            rnd[0] = rng_float(rng); rnd[1] = rng_float(rng); rnd[2] = rng_float(rng); rnd[3] = rng_float(rng);  // :330
+                            int lobe;
+                            if (!bsdf_sample(bsdf, surf, V, w, rnd, L, lobe)) {
+                                end_sample = true;
+                            } else {
+                                const float pdf = bsdf_pdf(bsdf, surf, L, V, w, lobe);
+                                if (pdf == 0.0f) {
+                                    end_sample = true;
+                                } else {
+                                    const f3 f = bsdf_eval(bsdf, surf, L, V, w, lobe);
+                                    if (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) {
+                                        end_sample = true;
+                                    } else {
+                                        T = T * make_f3(f.x / pdf, f.y / pdf, f.z / pdf);  // :346
+                                        if (fp.rr_enabled && bounce > 3) {                  // :348-356
+                                            const float p = pt_max(T.x, pt_max(T.y, T.z));
+                                            if (rng_float(rng) >= p) end_sample = true;
+                                            else T = make_f3(T.x / p, T.y / p, T.z / p);
+                                        }
+                                        if (!end_sample && luminance(T) <= fp.throughput_threshold) end_sample = true;  // :361
+                                        if (last) end_sample = true;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (!end_sample) {
+                        // spawn the next ray (Raytracing.hlsl:219-224)
+                        o = spawn_origin(hf.P, hf.N, hf.offset, L);
+                        d = L;
+                        bounce++;
+                        if (srad_changed) { scratch.sample_rad[slot] = make_float4(srad.x, srad.y, srad.z, 0.f); dirty = true; }
+                        emit = true;
+                        break;
+                    }
+                    // ---- end of sample: radiance += sampleRadiance (:373)
+                    if (!srad_loaded) {
+                        if (dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
+                    }
+                    f3 total = srad;
+                    if (fp.spp > 1) {
+                        f3 acc = make_f3(0.f, 0.f, 0.f);
+                        if (sample > 0) { const float4 r = scratch.radiance[slot]; acc = load3(r); }
+                        total = acc + srad;
+                    } else {
+                        total = make_f3(0.f, 0.f, 0.f) + srad;
+                    }
+                    sample++;
+                    if (sample == fp.spp) {  // :378-385
+                        f3 res = make_f3(0.f, 0.f, 0.f);
+                        if (is_finite(total.x) && is_finite(total.y) && is_finite(total.z)) {
+                            const float fs = (float)fp.spp;
+                            res = make_f3(total.x / fs, total.y / fs, total.z / fs);
+                        }
+                        out[pr.out_index] = make_float4(res.x, res.y, res.z, 1.0f);
+                        break;
+                    }
+                    scratch.radiance[slot] = make_float4(total.x, total.y, total.z, 0.f);
+                    // ---- regenerate: every sample restarts from the same primary ray / primary hit (:193-198)
+                    float tmin, tmax;
+                    primary_ray(fp.cam, pr.px, pr.py, pm.img_w, pm.img_h, o, d, tmin, tmax);
+                    const uint2 ph = scratch.primary_hit[slot];
+                    t = as_float(ph.x);
+                    id = ph.y;
+                    T = make_f3(1.f, 1.f, 1.f);
+                    bounce = 0;
+                    dirty = false;
+                }
+            }
+            flags = (bounce & kFlagBounceMask) | ((sample & kFlagSampleMask) << kFlagSampleShift) | (dirty ? kFlagDirty : 0u);
+        }
+        // ---- wave64 ballot + prefix compaction into the next queue; one atomic per block
+        const unsigned long long mask = __ballot(emit);
+        const uint32_t wave_n = __popcll(mask);
+        const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave_count[wave] = wave_n;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kShadeThreads / 64; w++) { const uint32_t c = s_wave_count[w]; s_wave_count[w] = total; total += c; }
+            s_block_base = total ? atomicAdd(count_out_ptr, total) : 0u;
+        }
+        __syncthreads();
+        if (emit) {
+            const uint32_t j = s_block_base + s_wave_count[wave] + prefix;
+            qout.q0[j] = make_float4(o.x, o.y, o.z, as_float(slot));
+            qout.q1[j] = make_float4(d.x, d.y, d.z, as_float(rng));
+            qout.q2[j] = make_float4(T.x, T.y, T.z, as_float(flags));
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ test hooks
+template <bool kLds, typename StackT>
+__global__ __launch_bounds__(kTraverseThreads) void trace_kernel(SceneView sv, const float* __restrict__ o, const float* __restrict__ d,
+                                                                 uint32_t n_rays, float tmin, float* __restrict__ out_t, uint32_t* __restrict__ out_id)
+{
+    extern __shared__ float4 smem[];
+    const float4* nodes = sv.nodes;
+    const float4* sph = sv.sph_sorted;
+    const uint32_t* ids = sv.sorted_id;
+    StackT* stack;
+    if (kLds) {
+        stage_scene(sv, smem);
+        nodes = smem;
+        sph = smem + sv.n_nodes * 4u;
+        ids = reinterpret_cast<const uint32_t*>(smem + sv.n_nodes * 4u + sv.n);
+        stack = reinterpret_cast<StackT*>(reinterpret_cast<char*>(smem) + scene_lds_bytes(sv.n_nodes, sv.n));
+    } else {
+        stack = reinterpret_cast<StackT*>(smem);
+    }
+    stack += threadIdx.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rays; i += gridDim.x * blockDim.x) {
+        float t;
+        uint32_t id;
+        closest_hit<StackT>(nodes, sph, ids, sv.n, make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
+                            tmin, kInf, stack, blockDim.x, t, id);
+        out_t[i] = t;
+        out_id[i] = id;
+    }
+}
+
+__global__ void brute_kernel(SceneView sv, const float* __restrict__ o, const float* __restrict__ d, uint32_t n_rays, float tmin,
+                             float* __restrict__ out_t, uint32_t* __restrict__ out_id)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rays; i += gridDim.x * blockDim.x) {
+        const f3 oo = make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dd = make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        float best = kInf;
+        uint32_t best_id = kMissId;
+        for (uint32_t k = 0; k < sv.n; k++) {
+            const float4 s = sv.sph[k];
+            float t;
+            if (intersect_sphere(oo, dd, tmin, best, make_f3(s.x, s.y, s.z), s.w, t)) { best = t; best_id = k; }
+        }
+        out_t[i] = best;
+        out_id[i] = best_id;
+    }
+}
+
+// Tile un-swizzle after the gather: gathered = [rank][max_tiles][ts*ts] float4 -> frame W*H float4.
+__global__ void unpack_tiles_kernel(const float4* __restrict__ gathered, float4* __restrict__ frame, uint32_t w, uint32_t h, uint32_t ts,
+                                    uint32_t tiles_x, uint32_t world, uint32_t max_tiles)
+{
+    const uint32_t n = w * h;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        const uint32_t x = p % w, y = p / w;
+        const uint32_t gt = (y / ts) * tiles_x + (x / ts);
+        const uint32_t rank = gt % world, k = gt / world;
+        frame[p] = gathered[((size_t)rank * max_tiles + k) * ts * ts + (y % ts) * ts + (x % ts)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launch wrappers
+static uint32_t traverse_lds_bytes(const SceneView& sv, uint32_t stack_elem)
+{
+    const uint32_t stack = kTraverseThreads * sv.stack_depth * stack_elem;
+    return (sv.lds_scene ? scene_lds_bytes(sv.n_nodes, sv.n) : 0u) + stack;
+}
+
+uint32_t traverse_lds_bytes_for(uint32_t n_nodes, uint32_t n, uint32_t depth, bool lds_scene)
+{
+    const uint32_t elem = n_nodes < 65536u ? 2u : 4u;
+    return (lds_scene ? scene_lds_bytes(n_nodes, n) : 0u) + kTraverseThreads * depth * elem;
+}
+
+#define PT_DISPATCH_TRAVERSE(KERNEL, GRID, STREAM, ...)                                                        \
+    do {                                                                                                        \
+        const bool small = sv.n_nodes < 65536u;                                                                 \
+        const uint32_t lds = traverse_lds_bytes(sv, small ? 2u : 4u);                                           \
+        if (lds > 65536u) {                                                                                     \
+            const void* fn = sv.lds_scene ? (small ? (const void*)KERNEL<true, uint16_t> : (const void*)KERNEL<true, uint32_t>)   \
+                                          : (small ? (const void*)KERNEL<false, uint16_t> : (const void*)KERNEL<false, uint32_t>); \
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+        }                                                                                                       \
+        if (sv.lds_scene) {                                                                                     \
+            if (small) hipLaunchKernelGGL((KERNEL<true, uint16_t>), dim3(GRID), dim3(kTraverseThreads), lds, STREAM, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<true, uint32_t>), dim3(GRID), dim3(kTraverseThreads), lds, STREAM, __VA_ARGS__);       \
+        } else {                                                                                                \
+            if (small) hipLaunchKernelGGL((KERNEL<false, uint16_t>), dim3(GRID), dim3(kTraverseThreads), lds, STREAM, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<false, uint32_t>), dim3(GRID), dim3(kTraverseThreads), lds, STREAM, __VA_ARGS__);       \
+        }                                                                                                       \
+    } while (0)
+
+hipError_t launch_primary(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& q, const Scratch& scratch,
+                          float4* out, uint32_t* count0, uint32_t grid, hipStream_t stream)
+{
+    PT_DISPATCH_TRAVERSE(primary_kernel, grid, stream, sv, pm, fp, q, scratch, out, count0);
+    return hipGetLastError();
+}
+
+hipError_t launch_traverse(const SceneView& sv, const RayQueue& q, const uint32_t* count_ptr, uint32_t grid, hipStream_t stream)
+{
+    PT_DISPATCH_TRAVERSE(traverse_kernel, grid, stream, sv, q, count_ptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_shade(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const RayQueue& qout,
+                        const Scratch& scratch, float4* out, const uint32_t* count_in, uint32_t* count_out, uint32_t grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(shade_kernel, dim3(grid), dim3(kShadeThreads), 0, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(const SceneView& sv, const float* o, const float* d, uint32_t n_rays, float tmin, int use_bvh, float* out_t,
+                        uint32_t* out_id, hipStream_t stream)
+{
+    const uint32_t grid = (n_rays + kTraverseThreads - 1) / kTraverseThreads < 2048u ? (n_rays + kTraverseThreads - 1) / kTraverseThreads : 2048u;
+    if (grid == 0) return hipSuccess;
+    if (use_bvh) {
+        PT_DISPATCH_TRAVERSE(trace_kernel, grid, stream, sv, o, d, n_rays, tmin, out_t, out_id);
+    } else {
+        hipLaunchKernelGGL(brute_kernel, dim3(grid), dim3(kTraverseThreads), 0, stream, sv, o, d, n_rays, tmin, out_t, out_id);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_tiles(const float4* gathered, float4* frame, uint32_t w, uint32_t h, uint32_t ts, uint32_t tiles_x, uint32_t world,
+                               uint32_t max_tiles, hipStream_t stream)
+{
+    const uint32_t n = w * h;
+    const uint32_t grid = (n + 255u) / 256u < 4096u ? (n + 255u) / 256u : 4096u;
+    hipLaunchKernelGGL(unpack_tiles_kernel, dim3(grid), dim3(256), 0, stream, gathered, frame, w, h, ts, tiles_x, world, max_tiles);
+    return hipGetLastError();
+}
+
+}  // namespace pt

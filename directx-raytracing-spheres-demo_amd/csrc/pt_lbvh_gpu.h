@@ -1,0 +1,30 @@
+// pt_lbvh_gpu.h -- device LBVH builder (Morton -> radix sort -> Karras hierarchy -> bottom-up refit).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pt_api.h"
+
+namespace pt {
+
+struct LbvhGpu;  // opaque: owns the builder's scratch buffers
+
+struct LbvhGpuInfo {
+    uint32_t depth;
+    float pad;
+    float bounds_min[3], bounds_max[3];
+    float build_ms;
+};
+
+// false until the device builder is linked in (then pt_build_accel uses it unless PT_FLAG_HOST_LBVH)
+bool lbvh_gpu_available();
+LbvhGpu* lbvh_gpu_create();
+void lbvh_gpu_destroy(LbvhGpu* b);
+
+// d_sph: n spheres in original order (float4 {cx,cy,cz,r}).  Outputs (device): nodes[n-1], sorted[n], sorted_id[n].
+// Synchronises the stream (the depth / bounds are read back).
+hipError_t lbvh_gpu_build(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode* d_nodes, float4* d_sorted, uint32_t* d_sorted_id,
+                          hipStream_t stream, LbvhGpuInfo* info);
+
+}  // namespace pt

@@ -1,0 +1,68 @@
+"""ctypes access to libpt_host.so: the C++ host mirror (scene generators, camera controller, Halton jitter)."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+from .types import MATERIAL_DTYPE, SPHERE_DTYPE, PtCamera, PtSceneData
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+
+SCENE_DEMO, SCENE_SMALL, SCENE_PROCEDURAL = 0, 1, 2
+
+
+class HostLib:
+    def __init__(self, path=None):
+        path = path or os.path.join(_PKG, "libpt_host.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        self.lib = C.CDLL(path)
+        self.lib.pth_scene.restype = C.c_int
+        self.lib.pth_scene.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(PtSceneData)]
+        self.lib.pth_camera.restype = None
+        self.lib.pth_camera.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(PtCamera)]
+        self.lib.pth_halton.restype = C.c_float
+        self.lib.pth_halton.argtypes = [C.c_uint32, C.c_uint32]
+        self.lib.pth_random_floats.restype = None
+        self.lib.pth_random_floats.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+
+    def scene(self, kind=SCENE_DEMO, seed=0, count=0):
+        """-> (spheres[SPHERE_DTYPE], materials[MATERIAL_DTYPE], PtSceneData)"""
+        n = C.c_uint32(0)
+        sd = PtSceneData()
+        rc = self.lib.pth_scene(kind, seed, count, None, None, 0, C.byref(n), C.byref(sd))
+        if rc:
+            raise ValueError(f"pth_scene size query failed ({rc})")
+        spheres = np.zeros(n.value, dtype=SPHERE_DTYPE)
+        materials = np.zeros(n.value, dtype=MATERIAL_DTYPE)
+        rc = self.lib.pth_scene(kind, seed, count, spheres.ctypes.data, materials.ctypes.data, n.value, C.byref(n), C.byref(sd))
+        if rc:
+            raise ValueError(f"pth_scene failed ({rc})")
+        return spheres, materials, sd
+
+    def camera(self, width, height, position=(0.0, 0.0, -15.0), look_at=None, hfov=math.pi / 2, jitter=True, jitter_index=0, jitter_count=8):
+        """Demo camera (MyScene.ixx:90; HFOV 90 deg, MyAppData.h:177); jitter = Halton2D(index + 1) - 0.5 cycling mod 8."""
+        cam = PtCamera()
+        pos = (C.c_float * 3)(*position)
+        la = (C.c_float * 3)(*look_at) if look_at is not None else None
+        self.lib.pth_camera(pos, la, hfov, width, height, 1 if jitter else 0, jitter_index, jitter_count, C.byref(cam))
+        return cam
+
+    def halton(self, index, base):
+        return float(self.lib.pth_halton(index, base))
+
+    def random_floats(self, seed, n):
+        out = np.zeros(n, dtype=np.float32)
+        self.lib.pth_random_floats(seed, n, out.ctypes.data)
+        return out
+
+
+_host = None
+
+
+def load_host():
+    global _host
+    if _host is None:
+        _host = HostLib()
+    return _host

@@ -1,0 +1,178 @@
+// MyScene.hpp -- host mirror of the demo scene of Source/MyScene.ixx:52-303 at t = 0,
+// plus the two benchmark scenes of SURVEY 8d that are derived from it (C1: 16 spheres, C5: 2^20 procedural).
+// Textures are a "next" row; the environment EXR is a missing LFS blob, so the environment
+// is the procedural sky (Scene.ixx:65, ShadingHelpers.hlsli:25-29).
+#pragma once
+
+#include <cmath>
+
+#include "Random.hpp"
+#include "Scene.hpp"
+
+namespace dxrs {
+
+namespace ObjectNames {
+inline constexpr const char* AlienMetal = "AlienMetal";
+inline constexpr const char* Earth = "Earth";
+inline constexpr const char* HarmonicOscillator = "HarmonicOscillator";
+inline constexpr const char* Moon = "Moon";
+inline constexpr const char* Sphere = "Sphere";
+inline constexpr const char* Star = "Star";
+}  // namespace ObjectNames
+
+struct Spring { static constexpr float PositionY = 0.5f, Period = 3; };  // MyScene.ixx:49
+
+namespace detail {
+
+struct Hero { const char* Name; Float3 Position; dxrs::Material Material; };
+
+inline std::vector<Hero> Heroes()  // MyScene.ixx:116-155
+{
+    std::vector<Hero> h(4);
+    h[0].Name = ObjectNames::AlienMetal; h[0].Position = { -2, 0.5f, 0 };
+    h[0].Material.BaseColor = { 1, 1, 1, 1 }; h[0].Material.Metallic = 1; h[0].Material.Roughness = 1;
+    h[1].Name = ""; h[1].Position = { 0, 0.5f, 0 };
+    h[1].Material.BaseColor = { 1, 1, 1, 1 }; h[1].Material.Roughness = 0; h[1].Material.Transmission = 1;
+    h[2].Name = ""; h[2].Position = { 0, 2, 0 };
+    h[2].Material.BaseColor = { 1, 1, 1, 1 }; h[2].Material.Roughness = 0.5f; h[2].Material.Transmission = 1;
+    h[3].Name = ""; h[3].Position = { 2, 0.5f, 0 };
+    h[3].Material.BaseColor = { 0.7f, 0.6f, 0.5f, 1 }; h[3].Material.Metallic = 1; h[3].Material.Roughness = 0.3f;
+    return h;
+}
+
+// One of the four random material classes of MyScene.ixx:196-226 (draw order = member order).
+inline Material RandomMaterial(Random& random)
+{
+    const auto RandomFloat4 = [&](float min) {
+        const auto v = random.Float3_(min);
+        return Float4{ v.x, v.y, v.z, 1 };
+    };
+    Material m;
+    if (const auto randomValue = random.Float(); randomValue < 0.3f) {
+        m.BaseColor = RandomFloat4(0.1f);
+    } else if (randomValue < 0.6f) {
+        m.BaseColor = RandomFloat4(0.1f);
+        m.Metallic = 1;
+        m.Roughness = random.Float(0, 0.5f);
+    } else if (randomValue < 0.8f) {
+        m.BaseColor = RandomFloat4(0.1f);
+        m.Roughness = random.Float(0, 0.5f);
+        m.Transmission = 1;
+    } else {
+        m.BaseColor = RandomFloat4(0.1f);
+        m.EmissiveStrength = random.Float(1, 10);
+        m.EmissiveColor = random.Float3_(0.2f);
+        m.Metallic = random.Float(0.4f);
+        m.Roughness = random.Float(0.3f);
+    }
+    return m;
+}
+
+// The 21x21 jittered grid of r = 0.075 spheres (MyScene.ixx:171-230); stops after max_count accepted.
+inline void AddGrid(SceneDesc& scene, unsigned seed, size_t max_count)
+{
+    const auto heroes = Heroes();
+    size_t accepted = 0;
+    Random random(seed);
+    for (int i = -10; i < 11 && accepted < max_count; i++) {
+        for (int j = -10; j < 11 && accepted < max_count; j++) {
+            constexpr float A = 0.5f;
+            Float3 position;
+            position.x = static_cast<float>(i) + 0.7f * random.Float();
+            // SimpleHarmonicMotion::Spring::CalculateDisplacement(A, omega, t = 0, phi = x) = A cos(omega*0 - x)  (PhysX.h:30-31)
+            position.y = Spring::PositionY + A * std::cos(0.0f - position.x);
+            position.z = static_cast<float>(j) - 0.7f * random.Float();
+
+            bool isOverlapping = false;
+            for (const auto& hero : heroes) {
+                const float dx = position.x - hero.Position.x, dy = position.y - hero.Position.y, dz = position.z - hero.Position.z;
+                if (std::sqrt(dx * dx + dy * dy + dz * dz) < 1) { isOverlapping = true; break; }
+            }
+            if (isOverlapping) continue;
+
+            RenderObjectDesc renderObject;
+            renderObject.Name = ObjectNames::HarmonicOscillator;
+            renderObject.Material = RandomMaterial(random);
+            renderObject.Position = position;
+            renderObject.Radius = 0.075f;
+            scene.RenderObjects.emplace_back(renderObject);
+            accepted++;
+        }
+    }
+}
+
+inline void AddHeroes(SceneDesc& scene)
+{
+    for (const auto& hero : Heroes()) {
+        RenderObjectDesc o;
+        o.Name = hero.Name; o.Position = hero.Position; o.Radius = 0.5f; o.Material = hero.Material;
+        scene.RenderObjects.emplace_back(o);
+    }
+}
+
+inline RenderObjectDesc Moon()  // MyScene.ixx:239-248
+{
+    RenderObjectDesc o; o.Name = ObjectNames::Moon; o.Position = { -4, 4, 0 }; o.Radius = 0.25f;
+    o.Material.BaseColor = { 1, 1, 1, 1 }; o.Material.Roughness = 0.8f; return o;
+}
+inline RenderObjectDesc Earth()  // MyScene.ixx:249-258
+{
+    RenderObjectDesc o; o.Name = ObjectNames::Earth; o.Position = { 0, 4, 0 }; o.Radius = 1;
+    o.Material.BaseColor = { 1, 1, 1, 1 }; o.Material.Roughness = 0.8f; return o;
+}
+inline RenderObjectDesc Star()  // MyScene.ixx:258-267: the mirror "ground"
+{
+    RenderObjectDesc o; o.Name = ObjectNames::Star; o.Position = { 0, -50.1f, 0 }; o.Radius = 50;
+    o.Material.BaseColor = { 0.5f, 0.5f, 0.5f, 1 }; o.Material.Metallic = 1; o.Material.Roughness = 0; return o;
+}
+
+}  // namespace detail
+
+// The demo default scene.  The reference seeds from random_device; the build takes a seed.
+struct MySceneDesc : SceneDesc {
+    explicit MySceneDesc(unsigned seed = 0)
+    {
+        Camera.Position.z = -15;  // MyScene.ixx:90
+        detail::AddHeroes(*this);
+        detail::AddGrid(*this, seed, ~size_t(0));
+        RenderObjects.emplace_back(detail::Moon());
+        RenderObjects.emplace_back(detail::Earth());
+        RenderObjects.emplace_back(detail::Star());
+    }
+};
+
+// 16 spheres = 4 heroes + first 10 accepted grid spheres (seed) + Earth-like + Star ground.
+struct SmallSceneDesc : SceneDesc {
+    explicit SmallSceneDesc(unsigned seed = 0)
+    {
+        Camera.Position.z = -15;
+        detail::AddHeroes(*this);
+        detail::AddGrid(*this, seed, 10);
+        RenderObjects.emplace_back(detail::Earth());
+        RenderObjects.emplace_back(detail::Star());
+    }
+};
+
+// `count` spheres, centres uniform in x,z in [-200,200], y in [0.1,20], radius log-uniform
+// in [0.02,0.2], material classes as the grid's 30/30/20/20 split, plus the Star ground as the last object.
+struct ProceduralSceneDesc : SceneDesc {
+    explicit ProceduralSceneDesc(uint32_t count, unsigned seed = 1)
+    {
+        Camera.Position.z = -15;
+        Random random(seed);
+        RenderObjects.reserve(static_cast<size_t>(count) + 1);
+        for (uint32_t i = 0; i < count; i++) {
+            RenderObjectDesc o;
+            o.Name = ObjectNames::Sphere;
+            o.Position.x = random.Float(-200, 200);
+            o.Position.y = random.Float(0.1f, 20);
+            o.Position.z = random.Float(-200, 200);
+            o.Radius = 0.02f * std::pow(10.0f, random.Float());
+            o.Material = detail::RandomMaterial(random);
+            RenderObjects.emplace_back(o);
+        }
+        RenderObjects.emplace_back(detail::Star());
+    }
+};
+
+}  // namespace dxrs

@@ -1,0 +1,145 @@
+/* pt_api.h -- C-ABI of the MI355X-native path-tracing hot path (libpt_hip.so).
+ *
+ * The reference has no plugin/FFI seam; its operator interface for this path is the
+ * pass-object pattern.  Each entry point below names the reference interface
+ * it replaces (citations into /root/reference):
+ *
+ *   pt_create / pt_destroy   Raytracing::Raytracing(CommandList&) + GBufferGeneration ctor: PSO / root
+ *                            signature / constant-buffer creation   Source/Raytracing.ixx:61-90, GBufferGeneration.ixx:54-68
+ *   pt_set_scene             Scene::Load + Refresh -> InstanceData/ObjectData upload
+ *                                                       Source/Scene.ixx:123-219, Source/App.cpp:977-1028
+ *   pt_build_accel           Scene::CreateAccelerationStructures (BLAS+TLAS via RTXMU)
+ *                                                       Source/Scene.ixx:225-284, RaytracingHelpers.ixx:28-74
+ *   pt_set_camera            commandList.Copy(*m_GPUBuffers.Camera, {m_camera})   Source/App.cpp:542-553
+ *   pt_set_constants         Raytracing::SetConstants(const GraphicsSettings&)    Source/Raytracing.ixx:92-104
+ *   pt_render                GBufferGeneration::Render + Raytracing::Render -> Dispatch / DispatchRays(W,H,1)
+ *                                                       Source/GBufferGeneration.ixx:80-117, Raytracing.ixx:106-112,228-249
+ *   pt_render_tiles / pt_unpack_tiles / pt_set_partition
+ *                            (no reference analogue: single adapter) tile partition for multi-GPU, SURVEY 8e
+ *   pt_last_error            ThrowIfFailed -> std::system_error text  Source/ErrorHelpers.ixx:16-32
+ *
+ * Conventions: plain pointers and sizes, status-code errors (no exceptions cross the boundary),
+ * opaque context, caller-owned host memory, callee-owned device memory.  A context is not
+ * thread-safe (the reference pass objects are driven from the main thread only, App.cpp:565-644).
+ * There is NO CPU fallback: pt_create fails with PT_ERR_NO_DEVICE when no HIP device exists.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include "pt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PtContext PtContext;
+
+typedef enum PtStatus {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARG = 1,
+    PT_ERR_NO_DEVICE = 2,
+    PT_ERR_HIP = 3,
+    PT_ERR_STATE = 4,       /* call order violated (e.g. render before build_accel) */
+    PT_ERR_UNSUPPORTED = 5, /* IsDIEnabled / Denoiser / environment texture requested */
+    PT_ERR_OOM = 6
+} PtStatus;
+
+typedef struct PtConfig {
+    int32_t device;         /* HIP device ordinal */
+    uint32_t tile_size;     /* multi-GPU tile edge in pixels; 0 -> 32 */
+    uint64_t stream;        /* hipStream_t to run on (e.g. torch's current stream); 0 -> context-owned stream */
+    uint32_t flags;         /* PT_FLAG_* */
+    uint32_t _reserved;
+} PtConfig;
+
+enum {
+    PT_FLAG_NO_LDS_SCENE = 1u,   /* never stage the BVH into LDS (debug / A-B) */
+    PT_FLAG_NO_GRAPH = 2u,       /* do not capture the per-frame launch sequence into a hipGraph */
+    PT_FLAG_HOST_LBVH = 4u       /* build the LBVH on the host instead of on the GPU (debug / A-B) */
+};
+
+typedef struct PtAccelInfo {
+    uint32_t leaf_count;     /* == sphere count */
+    uint32_t node_count;     /* internal nodes (leaf_count - 1, or 0 for a single sphere) */
+    uint32_t depth;          /* max root-to-leaf edge count */
+    uint32_t lds_resident;   /* 1 if traversal stages the whole BVH in LDS */
+    float bounds_min[3];
+    float bounds_max[3];
+    float build_ms;          /* device or host build time */
+    uint32_t _reserved;
+} PtAccelInfo;
+
+typedef struct PtStats {
+    uint64_t rays;              /* CastRay-equivalents traced, primaries included */
+    uint64_t paths;             /* (pixel, sample) pairs started */
+    uint64_t pixels;            /* pixels rendered by this call */
+    double ms_total;            /* device time of the whole call (HIP events on the context's stream) */
+    double ms_traverse;         /* summed device time of the traverse launches (0 unless profiling on) */
+    double ms_shade;            /* summed device time of the shade launches (0 unless profiling on) */
+    uint32_t traverse_launches;
+    uint32_t shade_launches;
+    uint64_t bytes_algorithmic; /* DESIGN.md byte model: per-ray queue traffic + per-path accumulate/store */
+} PtStats;
+
+/* BVH node as traversed on the device (DESIGN.md "LBVH layout"); exposed for structural tests. */
+typedef struct PtBvhNode {
+    float lo0[3], hi0[3];   /* child 0 AABB (padded) */
+    float lo1[3], hi1[3];   /* child 1 AABB (padded) */
+    int32_t child0, child1; /* >= 0: internal node index; < 0: leaf, Morton-sorted sphere index = ~child */
+    int32_t parent;         /* -1 for the root */
+    int32_t _pad;
+} PtBvhNode;
+
+PtStatus pt_create(const PtConfig *config, PtContext **out_ctx);
+void pt_destroy(PtContext *ctx);
+
+/* Copies n spheres + n materials (material i belongs to sphere i == ObjectIndex) and the scene constants. */
+PtStatus pt_set_scene(PtContext *ctx, const PtSphere *spheres, const PtMaterial *materials, uint32_t n,
+                      const PtSceneData *scene_data);
+/* Builds the LBVH over the current spheres.  info may be NULL. */
+PtStatus pt_build_accel(PtContext *ctx, PtAccelInfo *info);
+PtStatus pt_set_camera(PtContext *ctx, const PtCamera *camera);
+PtStatus pt_set_constants(PtContext *ctx, const PtGraphicsSettings *settings);
+
+/* Render rect (NULL = whole RenderSize) of the frame described by the current constants/camera.
+ * out: rect.w*rect.h float4 (r,g,b,1), row-major inside the rect; a HOST pointer if out_is_device == 0
+ * (synchronous copy-out), else a DEVICE pointer written on the context's stream (asynchronous).
+ * stats may be NULL; requesting stats synchronises the stream. */
+PtStatus pt_render(PtContext *ctx, const PtRect *rect, void *out, int out_is_device, PtStats *stats);
+
+/* Multi-GPU tile partition: the RenderSize image is cut into tile_size^2 tiles in row-major
+ * tile order; tile t belongs to rank (t % world).  pt_tiles_count returns this rank's tile count for the
+ * current RenderSize. */
+PtStatus pt_set_partition(PtContext *ctx, uint32_t rank, uint32_t world);
+uint32_t pt_tiles_count(PtContext *ctx, uint32_t rank);
+/* Render this rank's tiles into a packed DEVICE buffer of pt_tiles_count(rank) * tile_size^2 float4
+ * (tile-major, row-major inside a tile; pixels outside the image are zero).  Asynchronous unless stats != NULL. */
+PtStatus pt_render_tiles(PtContext *ctx, void *out_device_packed, PtStats *stats);
+/* Un-swizzle: given the concatenation [rank 0 tiles | rank 1 tiles | ...] where every rank's block is padded
+ * to max_tiles_per_rank tiles (what a gather of equal-sized buffers yields), write the full W*H float4 frame. */
+PtStatus pt_unpack_tiles(PtContext *ctx, const void *gathered_device, uint32_t max_tiles_per_rank,
+                         void *frame_device);
+
+/* Test / tooling hooks. */
+/* Closest hit of n rays against the current accel: o,d = n*3 floats (d unit length), tmin per call.
+ * Outputs host arrays t[n], id[n] (id = 0xFFFFFFFF on miss).  use_bvh = 0 runs the device brute-force kernel. */
+PtStatus pt_trace_rays(PtContext *ctx, const float *origins, const float *directions, uint32_t n, float tmin,
+                       int use_bvh, float *out_t, uint32_t *out_id);
+/* Copy the device BVH to host: nodes[node_count]; leaf child c < 0 refers to Morton-sorted index ~c, whose
+ * original sphere id is sorted_id[~c] (pt_accel_download_order: sorted_id[leaf_count]). */
+PtStatus pt_accel_download(PtContext *ctx, PtBvhNode *nodes, uint32_t capacity);
+PtStatus pt_accel_download_order(PtContext *ctx, uint32_t *sorted_id, uint32_t capacity);
+/* Host LBVH builder (the PT_FLAG_HOST_LBVH path), callable without a context or a GPU, for structural tests:
+ * nodes[n-1], sorted_id[n]; returns the tree depth through *depth. */
+PtStatus pt_lbvh_build_host(const PtSphere *spheres, uint32_t n, PtBvhNode *nodes, uint32_t *sorted_id, uint32_t *depth);
+/* Turn per-kernel hipEvent profiling on/off (adds event records around every launch; disables the graph). */
+PtStatus pt_set_profiling(PtContext *ctx, int enabled);
+PtStatus pt_synchronize(PtContext *ctx);
+
+const char *pt_last_error(PtContext *ctx);
+const char *pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_API_H */

@@ -1,0 +1,128 @@
+/* pt_types.h -- plain-C data layouts of the path-tracing hot path's API surface.
+ *
+ * These are byte-for-byte the structs the reference host uploads to the GPU for
+ * the bounce loop (citations are into /root/reference):
+ *
+ *   PtMaterial         == Material            Source/Material.ixx:12-20  (== Shaders/Material.hlsli:8-17), 64 B
+ *   PtCamera           == Camera              Source/Camera.ixx:16-36    (== Shaders/Camera.hlsli:5-25), 608 B payload
+ *   PtSceneData        == SceneData           Source/CommonShaderData.ixx:15-20 (== Shaders/Common.hlsli:7-13), 80 B payload
+ *   PtGraphicsSettings == _GraphicsSettings   Source/Raytracing.ixx:151-166 (== Shaders/Raytracing.hlsl:21-39), 80 B
+ *
+ * PtSphere replaces the reference's per-instance ObjectToWorld of the unit
+ * geosphere mesh (Source/Scene.ixx:188-203: scale = 2*radius, z flipped): the
+ * build intersects analytic spheres, so an instance is (centre, radius).
+ *
+ * No torch / HIP types appear here; this header is shared by the C-ABI
+ * (include/pt_api.h), the C++ host mirror and the CPU oracle (oracle/).
+ */
+#ifndef PT_TYPES_H
+#define PT_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PtSphere {
+    float cx, cy, cz; /* world-space centre (render space: PhysX z negated, Scene.ixx:197-199) */
+    float r;          /* radius > 0 */
+} PtSphere;
+
+/* Source/Material.ixx:10 */
+enum { PT_ALPHA_OPAQUE = 0, PT_ALPHA_MASK = 1, PT_ALPHA_BLEND = 2 };
+
+/* Source/Material.ixx:12-20; defaults are BaseColor (0,0,0,1), EmissiveStrength 1,
+ * EmissiveColor 0, Metallic 0, Roughness 0.5, IOR 1.5, Transmission 0, Opaque, AlphaCutoff 0.5 */
+typedef struct PtMaterial {
+    float BaseColor[4];      /*  0 */
+    float EmissiveStrength;  /* 16 */
+    float EmissiveColor[3];  /* 20 */
+    float Metallic;          /* 32 */
+    float Roughness;         /* 36 */
+    float IOR;               /* 40 */
+    float Transmission;      /* 44 */
+    uint32_t AlphaMode;      /* 48 */
+    float AlphaCutoff;       /* 52 */
+    uint32_t _pad[2];        /* 56 */
+} PtMaterial;
+
+/* Source/Camera.ixx:16-36. The bounce loop reads only Position, Right/Up/Forward
+ * (un-normalised, lens scaled), NearDepth, FarDepth and Jitter
+ * (Shaders/Raytracing.hlsl:114,126,138; Shaders/Camera.hlsli:27-41). */
+typedef struct PtCamera {
+    uint32_t IsNormalizedDepthReversed; /*   0 */
+    float PreviousPosition[3];          /*   4 */
+    float Position[3];                  /*  16 */
+    float _pad0;                        /*  28 */
+    float RightDirection[3];            /*  32 */
+    float _pad1;                        /*  44 */
+    float UpDirection[3];               /*  48 */
+    float _pad2;                        /*  60 */
+    float ForwardDirection[3];          /*  64 */
+    float ApertureRadius;               /*  76 */
+    float NearDepth;                    /*  80 */
+    float FarDepth;                     /*  84 */
+    float Jitter[2];                    /*  88 */
+    float Matrices[8][16];              /*  96: PreviousWorldToView, PreviousViewToProjection,
+                                                PreviousWorldToProjection, PreviousProjectionToView,
+                                                PreviousViewToWorld, WorldToProjection, ProjectionToView,
+                                                ViewToWorld -- unused by the bounce loop */
+} PtCamera;
+
+/* Source/CommonShaderData.ixx:15-20. EnvironmentLightColor.a < 0 selects the
+ * procedural sky (Shaders/ShadingHelpers.hlsli:25-29); the descriptor must be
+ * ~0u (environment textures are a "next" row). */
+typedef struct PtSceneData {
+    uint32_t IsStatic;                          /*  0 */
+    uint32_t IsEnvironmentLightTextureCubeMap;  /*  4 */
+    uint32_t EnvironmentLightTextureDescriptor; /*  8 */
+    uint32_t _pad;                              /* 12 */
+    float EnvironmentLightColor[4];             /* 16 */
+    float EnvironmentLightTransform[12];        /* 32: row-major float3x4 */
+} PtSceneData;
+
+/* GPU-side layout of GraphicsSettings, Source/Raytracing.ixx:151-166: HLSL bools are 4 bytes. */
+typedef struct PtGraphicsSettings {
+    uint32_t RenderSize[2];                      /*  0 */
+    uint32_t FrameIndex;                         /*  8 */
+    uint32_t Bounces;                            /* 12 */
+    uint32_t SamplesPerPixel;                    /* 16 */
+    float ThroughputThreshold;                   /* 20: reference default 1e-3 (Raytracing.ixx:33) */
+    uint32_t IsRussianRouletteEnabled;           /* 24 */
+    uint32_t IsShaderExecutionReorderingEnabled; /* 28: ignored (NV SER has no meaning here) */
+    uint32_t IsDIEnabled;                        /* 32: must be 0 (ReSTIR-DI dropped) */
+    uint32_t Denoiser;                           /* 36: must be 0 == Denoiser::None */
+    uint32_t _pad0[2];                           /* 40 */
+    uint32_t SHARC_Capacity;                     /* 48: SHARC block ignored (dropped) */
+    float SHARC_SceneScale;                      /* 52 */
+    float SHARC_RoughnessThreshold;              /* 56 */
+    uint32_t SHARC_IsAntiFireflyEnabled;         /* 60 */
+    uint32_t SHARC_IsHashGridVisualizationEnabled; /* 64 */
+    uint32_t _pad1[3];                           /* 68 */
+} PtGraphicsSettings;
+
+/* Pixel rectangle in render-target coordinates. */
+typedef struct PtRect {
+    uint32_t x, y, w, h;
+} PtRect;
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#ifdef __cplusplus
+static_assert(sizeof(PtSphere) == 16, "PtSphere layout");
+static_assert(sizeof(PtMaterial) == 64, "PtMaterial layout");
+static_assert(sizeof(PtCamera) == 608, "PtCamera layout");
+static_assert(sizeof(PtSceneData) == 80, "PtSceneData layout");
+static_assert(sizeof(PtGraphicsSettings) == 80, "PtGraphicsSettings layout");
+#else
+_Static_assert(sizeof(PtSphere) == 16, "PtSphere layout");
+_Static_assert(sizeof(PtMaterial) == 64, "PtMaterial layout");
+_Static_assert(sizeof(PtCamera) == 608, "PtCamera layout");
+_Static_assert(sizeof(PtSceneData) == 80, "PtSceneData layout");
+_Static_assert(sizeof(PtGraphicsSettings) == 80, "PtGraphicsSettings layout");
+#endif
+
+#endif /* PT_TYPES_H */

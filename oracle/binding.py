@@ -1,0 +1,110 @@
+"""ctypes access to the CPU ORACLE (oracle/libpt_oracle.so).  TEST INFRASTRUCTURE ONLY: import from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never from the product package."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+
+
+class OracleStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64)]
+
+
+class OracleBsdfOut(C.Structure):
+    _fields_ = [("lobe", C.c_int), ("valid", C.c_int), ("L", C.c_float * 3), ("pdf", C.c_float), ("f", C.c_float * 3), ("weights", C.c_float * 3)]
+
+
+class _Rect(C.Structure):
+    _fields_ = [("x", C.c_uint32), ("y", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32)]
+
+
+def declare_leaf_api(lib, prefix):
+    """Declare the leaf-function signatures shared by the oracle (prefix 'oracle_') and the host-compiled device
+    headers test shim (prefix 'dev_')."""
+    f, u32, vp = C.c_float, C.c_uint32, C.c_void_p
+    pf = C.POINTER(C.c_float)
+
+    def fn(name, res, args):
+        func = getattr(lib, prefix + name)
+        func.restype = res
+        func.argtypes = args
+        return func
+
+    fn("hash", u32, [u32])
+    fn("rng_init", u32, [u32, u32, u32])
+    fn("rng_next", u32, [C.POINTER(u32)])
+    fn("rng_float", f, [C.POINTER(u32)])
+    fn("sincos_2pi", None, [f, pf, pf])
+    fn("log2", f, [f])
+    fn("exp2", f, [f])
+    fn("pow", f, [f, f])
+    fn("from_srgb", f, [f])
+    fn("get_basis", None, [pf, pf, pf])
+    fn("cosine_ray", None, [pf, pf])
+    fn("vndf_ray", None, [pf, f, pf, pf])
+    fn("vndf_pdf", f, [pf, f, f])
+    fn("distribution_term", f, [f, f])
+    fn("geometry_term_mod", f, [f, f, f])
+    fn("fresnel_dielectric", f, [f, f])
+    fn("diffuse_term", f, [f, f, f, f])
+    fn("environment_term_rtg", None, [pf, f, f, pf])
+    fn("sky", None, [vp, pf, pf])
+    fn("intersect_sphere", C.c_int, [pf, pf, f, f, vp, pf])
+    fn("hit_frame", None, [pf, pf, f, vp, pf, pf, pf, C.POINTER(C.c_int)])
+    fn("spawn_origin", None, [pf, pf, f, pf, pf])
+    fn("primary_ray", None, [vp, u32, u32, u32, u32, pf, pf, pf, pf])
+    fn("bsdf_step", None, [vp, C.c_int, pf, pf, pf, C.POINTER(OracleBsdfOut)])
+
+
+class Oracle:
+    def __init__(self, path=None):
+        path = path or os.path.join(_DIR, "libpt_oracle.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not built: run `make -C oracle`")
+        self.lib = lib = C.CDLL(path)
+        vp, u32 = C.c_void_p, C.c_uint32
+        lib.oracle_render.restype = C.c_int
+        lib.oracle_render.argtypes = [vp, vp, u32, vp, vp, vp, C.POINTER(_Rect), u32, vp, C.POINTER(OracleStats), C.c_int]
+        lib.oracle_trace_pixel.restype = C.c_int
+        lib.oracle_trace_pixel.argtypes = [vp, vp, u32, vp, vp, vp, u32, u32, vp, u32, C.POINTER(u32)]
+        lib.oracle_halton.restype = C.c_float
+        lib.oracle_halton.argtypes = [u32, u32]
+        declare_leaf_api(lib, "oracle_")
+
+    def render(self, spheres, materials, scene_data, camera, gs, rect=None, row_step=1, threads=1):
+        """-> (rgba float32 array (h, w, 4), OracleStats).  Rows skipped by row_step are left as NaN."""
+        spheres = np.ascontiguousarray(spheres)
+        materials = np.ascontiguousarray(materials)
+        if rect is None:
+            rect = (0, 0, gs.RenderSize[0], gs.RenderSize[1])
+        r = _Rect(*rect)
+        out = np.full((r.h, r.w, 4), np.nan, dtype=np.float32)
+        stats = OracleStats()
+        rc = self.lib.oracle_render(spheres.ctypes.data, materials.ctypes.data, len(spheres), C.addressof(scene_data), C.addressof(camera),
+                                    C.addressof(gs), C.byref(r), row_step, out.ctypes.data, C.byref(stats), threads)
+        if rc:
+            raise RuntimeError(f"oracle_render failed ({rc})")
+        return out, stats
+
+    def trace_pixel(self, spheres, materials, scene_data, camera, gs, px, py, max_events=4096):
+        spheres = np.ascontiguousarray(spheres)
+        materials = np.ascontiguousarray(materials)
+        ev = np.zeros((max_events, 16), dtype=np.float32)
+        n = C.c_uint32(0)
+        rc = self.lib.oracle_trace_pixel(spheres.ctypes.data, materials.ctypes.data, len(spheres), C.addressof(scene_data), C.addressof(camera),
+                                         C.addressof(gs), px, py, ev.ctypes.data, max_events, C.byref(n))
+        if rc:
+            raise RuntimeError(f"oracle_trace_pixel failed ({rc})")
+        return ev[: n.value]
+
+
+_oracle = None
+
+
+def load_oracle():
+    global _oracle
+    if _oracle is None:
+        _oracle = Oracle()
+    return _oracle

@@ -1,0 +1,798 @@
+/* pt_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See pt_oracle.h.
+ *
+ * PARITY UNPINNED (no reference tests / golden vectors exist; MathLib is absent).
+ *
+ * Build: gcc -O2 -ffp-contract=off -mfma (see oracle/Makefile).  Every floating-point
+ * operation below is written in the exact order of DESIGN.md "Frozen arithmetic spec";
+ * fused multiply-adds appear ONLY where spelled FMA(); min/max/saturate are explicit
+ * ternaries so NaN behaviour is defined.  Citations are into /root/reference.
+ */
+#include "pt_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 V3(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 v_add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 v_sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v_mul(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 v_scale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline v3 v_neg(v3 a) { return V3(-a.x, -a.y, -a.z); }
+/* s*a + b, one fma per component */
+static inline v3 v_mad(float s, v3 a, v3 b) { return V3(FMA(s, a.x, b.x), FMA(s, a.y, b.y), FMA(s, a.z, b.z)); }
+/* spec dot: fma(a.z,b.z, fma(a.y,b.y, a.x*b.x)) */
+static inline float v_dot(v3 a, v3 b) { return FMA(a.z, b.z, FMA(a.y, b.y, a.x * b.x)); }
+/* spec normalize: v * (1/sqrt(dot(v,v))) */
+static inline v3 v_normalize(v3 a) { float inv = 1.0f / sqrtf(v_dot(a, a)); return v_scale(a, inv); }
+static inline float f_abs(float x) { return fabsf(x); }
+static inline float f_max(float a, float b) { return a > b ? a : b; }
+static inline float f_min(float a, float b) { return a < b ? a : b; }
+/* HLSL saturate: NaN -> 0 */
+static inline float f_sat(float x) { return !(x > 0.0f) ? 0.0f : (x > 1.0f ? 1.0f : x); }
+static inline float f_sqrt01(float x) { return sqrtf(f_sat(x)); }       /* Math::Sqrt01 */
+static inline float f_sign(float x) { return x >= 0.0f ? 1.0f : -1.0f; } /* Math::Sign, Sign(0)=+1 */
+static inline int f_finite(float x) { return isfinite(x); }
+static inline float as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+#define PT_PI 3.14159265358979323846f
+#define PT_INV_PI (1.0f / PT_PI)
+#define PT_OFFSET_SCALE 1.52587890625e-05f /* 2^-16, build-defined sphere spawn offset */
+#define PT_MIN_ROUGHNESS 2e-3f             /* BxDF.hlsli:19 */
+
+/* ------------------------------------------------------------------ RNG (Appendix A) */
+uint32_t oracle_hash(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+static inline uint32_t hash_combine(uint32_t seed, uint32_t v)
+{
+    return seed ^ (oracle_hash(v) + 0x9E3779B9u + (seed << 6) + (seed >> 2));
+}
+/* Rng::Hash::Initialize(pixel, frame): Raytracing.hlsl:108 */
+uint32_t oracle_rng_init(uint32_t px, uint32_t py, uint32_t frame)
+{
+    return hash_combine(oracle_hash(frame + 0x035F9F29u), (px << 16) | py);
+}
+uint32_t oracle_rng_next(uint32_t *state) { *state = oracle_hash(*state); return *state; }
+/* GetFloat = 2 - asfloat((u>>9)|0x3F800000), range (0,1] */
+float oracle_rng_float(uint32_t *state)
+{
+    uint32_t u = oracle_rng_next(state);
+    return 2.0f - as_float((u >> 9) | 0x3F800000u);
+}
+
+/* ------------------------------------------------------------------ Halton (HaltonSampler.ixx:32-34) */
+float oracle_halton(uint32_t index, uint32_t base)
+{
+    if (base == 2) { /* bit reversal * 2^-32 */
+        uint32_t v = index;
+        v = (v << 16) | (v >> 16);
+        v = ((v & 0x00FF00FFu) << 8) | ((v & 0xFF00FF00u) >> 8);
+        v = ((v & 0x0F0F0F0Fu) << 4) | ((v & 0xF0F0F0F0u) >> 4);
+        v = ((v & 0x33333333u) << 2) | ((v & 0xCCCCCCCCu) >> 2);
+        v = ((v & 0x55555555u) << 1) | ((v & 0xAAAAAAAAu) >> 1);
+        return (float)v * 2.3283064365386963e-10f;
+    }
+    float f = 1.0f, r = 0.0f, fb = (float)base;
+    uint32_t i = index;
+    while (i > 0) {
+        f = f / fb;
+        r = r + f * (float)(i % base);
+        i = i / base;
+    }
+    return r;
+}
+
+/* ------------------------------------------------------------------ build-defined sincos / log2 / exp2 / pow */
+/* sin, cos of 2*pi*u, u in [0,1].  Quadrant reduction on u (exact), then odd/even polynomials
+ * on [-pi/4, pi/4] evaluated with fma Horner chains. */
+void oracle_sincos_2pi(float u, float *so, float *co)
+{
+    float x = u * 4.0f;
+    float k = floorf(x + 0.5f);
+    float y = x - k;                       /* [-0.5, 0.5], exact */
+    float z = y * 1.57079632679489661923f; /* pi/2 */
+    float z2 = z * z;
+    float ps = FMA(z2, FMA(z2, FMA(z2, 2.7557314297e-06f, -1.9841270114e-04f), 8.3333337680e-03f), -1.6666667163e-01f);
+    float s = FMA(z * z2, ps, z);
+    float pc = FMA(z2, FMA(z2, FMA(z2, -2.7557314297e-07f, 2.4801587642e-05f), -1.3888889225e-03f), 4.1666667908e-02f);
+    float c = FMA(z2 * z2, pc, FMA(z2, -0.5f, 1.0f));
+    int q = ((int)k) & 3;
+    float rs, rc;
+    if (q == 0) { rs = s; rc = c; }
+    else if (q == 1) { rs = c; rc = -s; }
+    else if (q == 2) { rs = -s; rc = -c; }
+    else { rs = -c; rc = s; }
+    *so = rs; *co = rc;
+}
+
+/* log2 for finite x > 0 (normal numbers) */
+float oracle_log2(float x)
+{
+    uint32_t b = as_uint(x);
+    int e = (int)(b >> 23) - 127;
+    float m = as_float((b & 0x007FFFFFu) | 0x3F800000u); /* [1,2) */
+    if (m > 1.41421356237309504880f) { m = m * 0.5f; e = e + 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float s2 = s * s;
+    float p = FMA(s2, FMA(s2, FMA(s2, FMA(s2, 0.111111111f, 0.142857143f), 0.2f), 0.333333333f), 1.0f);
+    float ln_m = (2.0f * s) * p;
+    return FMA(ln_m, 1.44269504088896340736f, (float)e);
+}
+
+/* 2^y for |y| < 126 */
+float oracle_exp2(float y)
+{
+    float k = floorf(y + 0.5f);
+    float f = y - k; /* [-0.5, 0.5] */
+    float t = f * 0.69314718055994530942f;
+    float p = FMA(t, FMA(t, FMA(t, FMA(t, FMA(t, FMA(t, FMA(t, 1.98412698e-04f, 1.38888889e-03f), 8.33333333e-03f),
+                  4.16666667e-02f), 1.66666667e-01f), 0.5f), 1.0f), 1.0f);
+    int ki = (int)k;
+    return p * as_float((uint32_t)(ki + 127) << 23);
+}
+
+float oracle_pow(float x, float y) { return oracle_exp2(y * oracle_log2(x)); }
+
+/* Color::FromSrgb, one channel (c saturated) */
+float oracle_from_srgb(float c)
+{
+    c = f_sat(c);
+    if (c <= 0.04045f) return c / 12.92f;
+    return oracle_pow((c + 0.055f) / 1.055f, 2.4f);
+}
+
+static inline float luminance(v3 c) { return v_dot(c, V3(0.2126f, 0.7152f, 0.0722f)); }
+
+/* ------------------------------------------------------------------ Geometry (Appendix A) */
+typedef struct { v3 T, B, N; } basis3;
+
+/* Geometry::GetBasis: SurfaceVectors.hlsli:14 */
+static basis3 get_basis(v3 N)
+{
+    float sz = f_sign(N.z);
+    float a = 1.0f / (sz + N.z);
+    float ya = N.y * a;
+    float b = N.x * ya;
+    float c = N.x * sz;
+    basis3 m;
+    m.T = V3(c * N.x * a - 1.0f, sz * b, c);
+    m.B = V3(b, N.y * ya - sz, N.y);
+    m.N = N;
+    return m;
+}
+void oracle_get_basis(const float n[3], float t[3], float b[3])
+{
+    basis3 m = get_basis(V3(n[0], n[1], n[2]));
+    t[0] = m.T.x; t[1] = m.T.y; t[2] = m.T.z;
+    b[0] = m.B.x; b[1] = m.B.y; b[2] = m.B.z;
+}
+/* world -> local */
+static inline v3 rotate_vector(basis3 m, v3 v) { return V3(v_dot(m.T, v), v_dot(m.B, v), v_dot(m.N, v)); }
+/* local -> world: v.x*T + v.y*B + v.z*N */
+static inline v3 rotate_vector_inverse(basis3 m, v3 v)
+{
+    return V3(FMA(v.z, m.N.x, FMA(v.y, m.B.x, v.x * m.T.x)),
+              FMA(v.z, m.N.y, FMA(v.y, m.B.y, v.x * m.T.y)),
+              FMA(v.z, m.N.z, FMA(v.y, m.B.z, v.x * m.T.z)));
+}
+/* HLSL reflect(i,n) = i - 2*dot(n,i)*n */
+static inline v3 reflect3(v3 i, v3 n) { float k = 2.0f * v_dot(n, i); return v_mad(-k, n, i); }
+/* HLSL refract(i,n,eta) */
+static inline v3 refract3(v3 i, v3 n, float eta)
+{
+    float c = v_dot(n, i);
+    float k = 1.0f - eta * eta * (1.0f - c * c);
+    if (k < 0.0f) return V3(0.0f, 0.0f, 0.0f);
+    float a = FMA(eta, c, sqrtf(k));
+    return V3(FMA(-a, n.x, eta * i.x), FMA(-a, n.y, eta * i.y), FMA(-a, n.z, eta * i.z));
+}
+
+/* ------------------------------------------------------------------ sampling + BRDF terms (Appendix A) */
+static v3 cosine_ray(float u0, float u1)
+{
+    float s, c;
+    oracle_sincos_2pi(u0, &s, &c);
+    float cos_t = f_sqrt01(u1);
+    float sin_t = f_sqrt01(1.0f - cos_t * cos_t);
+    return V3(sin_t * c, sin_t * s, cos_t);
+}
+void oracle_cosine_ray(const float u[2], float out[3])
+{
+    v3 r = cosine_ray(u[0], u[1]); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+/* ImportanceSampling::VNDF::GetRay (spherical caps) */
+static v3 vndf_ray(float u0, float u1, float roughness, v3 Vl)
+{
+    float m = roughness * roughness;
+    v3 Vh = v_normalize(V3(m * Vl.x, m * Vl.y, Vl.z));
+    float s, c;
+    oracle_sincos_2pi(u0, &s, &c);
+    float z = FMA(1.0f - u1, 1.0f + Vh.z, -Vh.z);
+    float sr = f_sqrt01(1.0f - z * z);
+    v3 Nh = V3(FMA(sr, c, Vh.x), FMA(sr, s, Vh.y), z + Vh.z);
+    return v_normalize(V3(m * Nh.x, m * Nh.y, f_max(Nh.z, 1e-7f)));
+}
+void oracle_vndf_ray(const float u[2], float roughness, const float vl[3], float out[3])
+{
+    v3 r = vndf_ray(u[0], u[1], roughness, V3(vl[0], vl[1], vl[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+/* BRDF::DistributionTerm (GGX) */
+float oracle_distribution_term(float roughness, float noh)
+{
+    /* robust form (upstream MathLib's default branch): the textbook ((NoH*m2 - NoH)*NoH + 1) form of SURVEY
+     * Appendix A evaluates to 0 when NoH rounds to 1 at roughness 2e-3 -> D = inf -> f/pdf = NaN on the demo's
+     * roughness-0 ground mirror (DESIGN.md "Frozen arithmetic spec", deviation D1). */
+    float m = roughness * roughness;
+    float m2 = m * m;
+    float t = FMA(-(noh * noh), 0.99999994f - m2, 1.0f);
+    float a = f_max(m, 1e-6f) / t;
+    return (a * a) / PT_PI;
+}
+/* VNDF::GetPDF(Vlocal, NoH, roughness) = D * G1(|Vl.z|) / (4 |Vl.z|) */
+float oracle_vndf_pdf(const float vl[3], float noh, float roughness)
+{
+    float m = roughness * roughness;
+    float m2 = m * m;
+    float nov = f_abs(vl[2]);
+    float g1 = (2.0f * nov) / (nov + sqrtf(FMA(1.0f - m2, nov * nov, m2)));
+    float d = oracle_distribution_term(roughness, noh);
+    return d * g1 / (4.0f * nov);
+}
+/* BRDF::GeometryTermMod (Smith height-correlated / (4 NoL NoV)) */
+float oracle_geometry_term_mod(float roughness, float nol, float nov)
+{
+    float m = roughness * roughness;
+    float m2 = m * m;
+    float a = nov * f_sqrt01(FMA(FMA(-m2, nol, nol), nol, m2));
+    float b = nol * f_sqrt01(FMA(FMA(-m2, nov, nov), nov, m2));
+    return 0.5f / (a + b);
+}
+static inline float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
+/* BRDF::FresnelTerm (Schlick): F0 + (1-F0)(1-VoH)^5 */
+static inline v3 fresnel_schlick(v3 f0, float voh)
+{
+    float p = pow5(1.0f - voh);
+    return V3(FMA(1.0f - f0.x, p, f0.x), FMA(1.0f - f0.y, p, f0.y), FMA(1.0f - f0.z, p, f0.z));
+}
+/* BRDF::FresnelTerm_Dielectric(eta, VoN) */
+float oracle_fresnel_dielectric(float eta, float von)
+{
+    float sa2 = eta * eta * (1.0f - von * von);
+    float ca = f_sqrt01(1.0f - sa2);
+    float rs = (eta * von - ca) / (eta * von + ca);
+    float rp = (eta * ca - von) / (eta * ca + von);
+    return 0.5f * (rs * rs + rp * rp);
+}
+/* BRDF::DiffuseTerm (Burley) */
+float oracle_diffuse_term(float roughness, float nol, float nov, float voh)
+{
+    float f = FMA(2.0f * voh * voh, roughness, -0.5f);
+    float fdv = FMA(f, pow5(1.0f - nov), 1.0f);
+    float fdl = FMA(f, pow5(1.0f - nol), 1.0f);
+    return fdv * fdl * PT_INV_PI;
+}
+/* BRDF::EnvironmentTerm_Rtg (RT Gems ch.32 fit) */
+static v3 environment_term_rtg(v3 f0, float nov, float roughness)
+{
+    float m = roughness * roughness;
+    float x1 = nov, x2 = nov * nov, x3 = nov * x2;
+    float y1 = m, y2 = m * m, y3 = m * y2;
+    /* mul(M, X) rows dotted with Y, all as left-to-right fma chains */
+    float b_num = FMA(FMA(-0.755907f, x1, 1.29678f), y1, FMA(-1.28514f, x1, 0.99044f));
+    float b_den = FMA(FMA(316.627f, x3, FMA(626.13f, x1, 121.563f)), y3,
+                      FMA(FMA(222.592f, x3, FMA(-27.0302f, x1, 20.3225f)), y1,
+                          FMA(59.4188f, x3, FMA(2.92338f, x1, 1.0f))));
+    float s_num = FMA(FMA(-9.04756f, x1, 9.0632f), y1, FMA(3.32707f, x1, 0.0365463f));
+    float s_den = FMA(FMA(-20.2123f, x3, FMA(19.7886f, x2, 5.56589f)), y3,
+                      FMA(FMA(9.22949f, x3, FMA(-16.3174f, x2, 9.04401f)), y1,
+                          FMA(-1.36772f, x3, FMA(3.59685f, x2, 1.0f))));
+    float bias = b_num / b_den;
+    float scale = s_num / s_den;
+    (void)y2;
+    return V3(f_sat(FMA(f0.x, scale, bias)), f_sat(FMA(f0.y, scale, bias)), f_sat(FMA(f0.z, scale, bias)));
+}
+void oracle_environment_term_rtg(const float f0[3], float nov, float roughness, float out[3])
+{
+    v3 r = environment_term_rtg(V3(f0[0], f0[1], f0[2]), nov, roughness);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+/* ------------------------------------------------------------------ environment (ShadingHelpers.hlsli:11-30) */
+static v3 environment_color(const PtSceneData *sd, v3 d)
+{
+    if (sd->EnvironmentLightColor[3] >= 0.0f)
+        return V3(sd->EnvironmentLightColor[0], sd->EnvironmentLightColor[1], sd->EnvironmentLightColor[2]);
+    float t = (d.y + 1.0f) * 0.5f;
+    /* lerp(1, (0.5,0.7,1), t) = 1 + t*(b-1) */
+    float r = FMA(t, 0.5f - 1.0f, 1.0f), g = FMA(t, 0.7f - 1.0f, 1.0f), b = FMA(t, 1.0f - 1.0f, 1.0f);
+    return V3(oracle_from_srgb(r), oracle_from_srgb(g), oracle_from_srgb(b));
+}
+void oracle_sky(const PtSceneData *scene, const float dir[3], float out[3])
+{
+    v3 c = environment_color(scene, V3(dir[0], dir[1], dir[2])); out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+
+/* ------------------------------------------------------------------ ray-sphere (build-defined, replaces CastRay) */
+/* Stable quadratic for a unit-length direction.  Nearest root t with tmin < t < tmax. */
+static int intersect_sphere(v3 o, v3 d, float tmin, float tmax, const PtSphere *s, float *t_out)
+{
+    v3 f = v_sub(o, V3(s->cx, s->cy, s->cz));
+    float bp = -v_dot(f, d);
+    v3 l = v_mad(bp, d, f);
+    float r2 = s->r * s->r;
+    float disc = r2 - v_dot(l, l);
+    if (!(disc >= 0.0f)) return 0;
+    float sq = sqrtf(disc);
+    float q = bp + (bp >= 0.0f ? sq : -sq);
+    float cc = v_dot(f, f) - r2;
+    float ta = cc / q;
+    float tb = q;
+    float t0 = ta < tb ? ta : tb;
+    float t1 = ta < tb ? tb : ta;
+    float t = t0 > tmin ? t0 : t1;
+    if (t > tmin && t < tmax) { *t_out = t; return 1; }
+    return 0;
+}
+int oracle_intersect_sphere(const float o[3], const float d[3], float tmin, float tmax, const PtSphere *s, float *t)
+{
+    return intersect_sphere(V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), tmin, tmax, s, t);
+}
+
+typedef struct {
+    int hit;
+    uint32_t id;
+    float t;
+    v3 P, N;      /* re-projected position, outward geometric normal */
+    float offset; /* spawn offset */
+    int front;
+    v3 shadingN;  /* N or -N (HitInfo.hlsli:60-64) */
+} hit_t;
+
+/* closest hit, brute force; ties -> lowest id (strict < in id order) */
+static void cast_ray(const PtSphere *sph, uint32_t n, v3 o, v3 d, float tmin, float tmax, hit_t *h)
+{
+    float best = tmax;
+    uint32_t best_id = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < n; i++) {
+        float t;
+        if (intersect_sphere(o, d, tmin, best, &sph[i], &t)) { best = t; best_id = i; }
+    }
+    h->hit = best_id != 0xFFFFFFFFu;
+    h->id = best_id;
+    h->t = best;
+    if (h->hit) {
+        const PtSphere *s = &sph[best_id];
+        v3 C = V3(s->cx, s->cy, s->cz);
+        v3 P0 = v_mad(best, d, o);
+        v3 N = v_normalize(v_sub(P0, C));
+        v3 P = v_mad(s->r, N, C);
+        float mx = f_max(f_max(f_abs(P.x), f_abs(P.y)), f_max(f_abs(P.z), s->r));
+        h->P = P; h->N = N;
+        h->offset = PT_OFFSET_SCALE * mx;
+        h->front = v_dot(N, d) < 0.0f;
+        h->shadingN = h->front ? N : v_neg(N);
+    }
+}
+void oracle_hit_frame(const float o[3], const float d[3], float t, const PtSphere *s,
+                      float P[3], float N[3], float *offset, int *front)
+{
+    v3 oo = V3(o[0], o[1], o[2]), dd = V3(d[0], d[1], d[2]);
+    v3 C = V3(s->cx, s->cy, s->cz);
+    v3 P0 = v_mad(t, dd, oo);
+    v3 n = v_normalize(v_sub(P0, C));
+    v3 p = v_mad(s->r, n, C);
+    float mx = f_max(f_max(f_abs(p.x), f_abs(p.y)), f_max(f_abs(p.z), s->r));
+    P[0] = p.x; P[1] = p.y; P[2] = p.z; N[0] = n.x; N[1] = n.y; N[2] = n.z;
+    *offset = PT_OFFSET_SCALE * mx;
+    *front = v_dot(n, dd) < 0.0f;
+}
+/* HitInfo::GetSafeWorldRayOrigin (HitInfo.hlsli:96-99) + OffsetSpawnPoint (SelfIntersectionAvoidance.hlsli:113-117) */
+static inline v3 spawn_origin(v3 P, v3 N, float offset, v3 L)
+{
+    float sg = f_sign(v_dot(L, N));
+    return v_mad(offset, v_scale(N, sg), P);
+}
+void oracle_spawn_origin(const float P[3], const float N[3], float offset, const float L[3], float out[3])
+{
+    v3 r = spawn_origin(V3(P[0], P[1], P[2]), V3(N[0], N[1], N[2]), offset, V3(L[0], L[1], L[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+/* ------------------------------------------------------------------ camera (Camera.hlsli:27-41, Math.hlsli:7-15) */
+static void primary_ray(const PtCamera *cam, uint32_t px, uint32_t py, uint32_t w, uint32_t h,
+                        v3 *o, v3 *d, float *tmin, float *tmax)
+{
+    float u = ((float)px + 0.5f + cam->Jitter[0]) / (float)w;
+    float v = ((float)py + 0.5f + cam->Jitter[1]) / (float)h;
+    float nx = FMA(u, 2.0f, -1.0f);
+    float ny = FMA(v, -2.0f, 1.0f);
+    v3 R = V3(cam->RightDirection[0], cam->RightDirection[1], cam->RightDirection[2]);
+    v3 U = V3(cam->UpDirection[0], cam->UpDirection[1], cam->UpDirection[2]);
+    v3 F = V3(cam->ForwardDirection[0], cam->ForwardDirection[1], cam->ForwardDirection[2]);
+    v3 dir = v_add(v_mad(ny, U, v_scale(R, nx)), F);
+    dir = v_normalize(dir);
+    float inv_cos = 1.0f / v_dot(v_normalize(F), dir);
+    *o = V3(cam->Position[0], cam->Position[1], cam->Position[2]);
+    *d = dir;
+    *tmin = cam->NearDepth * inv_cos;
+    *tmax = cam->FarDepth * inv_cos;
+}
+void oracle_primary_ray(const PtCamera *cam, uint32_t px, uint32_t py, uint32_t w, uint32_t h,
+                        float o[3], float d[3], float *tmin, float *tmax)
+{
+    v3 oo, dd;
+    primary_ray(cam, px, py, w, h, &oo, &dd, tmin, tmax);
+    o[0] = oo.x; o[1] = oo.y; o[2] = oo.z; d[0] = dd.x; d[1] = dd.y; d[2] = dd.z;
+}
+
+/* ------------------------------------------------------------------ BSDF (BxDF.hlsli) */
+enum { LOBE_DIFFUSE = 0, LOBE_SPECULAR = 1, LOBE_TRANSMISSION = 2 };
+
+typedef struct {
+    v3 BaseColor; float Metallic; v3 Albedo; float Roughness, IORi, IORo; v3 F0; float Transmission;
+} bsdf_t;
+
+/* BSDFSample::Initialize, BxDF.hlsli:45-66 (pow(x,2) restated as x*x) */
+static void bsdf_init(bsdf_t *b, v3 base, float metallic, float roughness, float ior, float transmission, int front)
+{
+    b->BaseColor = base;
+    b->Metallic = metallic;
+    b->Albedo = v_scale(base, 1.0f - metallic);
+    b->Roughness = f_max(PT_MIN_ROUGHNESS, roughness);
+    b->IORi = 1.0f; b->IORo = ior;
+    if (!front) { b->IORi = ior; b->IORo = 1.0f; }
+    float r = (b->IORi - b->IORo) / (b->IORi + b->IORo);
+    float f0d = r * r;
+    /* lerp(f0d, baseColor, metallic) */
+    b->F0 = V3(FMA(metallic, base.x - f0d, f0d), FMA(metallic, base.y - f0d, f0d), FMA(metallic, base.z - f0d, f0d));
+    b->Transmission = transmission;
+}
+
+typedef struct { v3 FrontNg, Ns; basis3 basis; } surf_t;
+
+/* SurfaceVectors::Initialize, SurfaceVectors.hlsli:10-15 */
+static void surf_init(surf_t *s, int front, v3 Ng, v3 Ns)
+{
+    s->FrontNg = front ? Ng : v_neg(Ng);
+    s->Ns = Ns;
+    s->basis = get_basis(Ns);
+}
+
+/* EstimateDiffuseProbability, BxDF.hlsli:21-34 */
+static float estimate_diffuse_probability(v3 albedo, v3 f0, float roughness, float nov)
+{
+    v3 fe = environment_term_rtg(f0, nov, roughness);
+    float diffuse = luminance(v_mul(albedo, V3(1.0f - fe.x, 1.0f - fe.y, 1.0f - fe.z)));
+    float specular = luminance(fe);
+    float sum = diffuse + specular;
+    float p = sum > 0.0f ? diffuse / sum : 1.0f;
+    if (0.0f < p && p < 1.0f) { /* clamp(p, 0.05, 0.95) */
+        p = p < 0.05f ? 0.05f : (p > 0.95f ? 0.95f : p);
+    }
+    return p;
+}
+
+/* ComputeLobeWeights, BxDF.hlsli:184-196 */
+static void lobe_weights(const bsdf_t *b, const surf_t *s, v3 V, float w[3])
+{
+    float nov = f_abs(v_dot(s->Ns, V));
+    float wt = b->Transmission * (1.0f - b->Metallic);
+    float wr = 1.0f - wt;
+    float pd = estimate_diffuse_probability(b->Albedo, b->F0, b->Roughness, nov);
+    float ps = 1.0f - pd;
+    w[LOBE_DIFFUSE] = pd * wr;
+    w[LOBE_SPECULAR] = ps * wr;
+    w[LOBE_TRANSMISSION] = wt;
+}
+
+/* FindLobe, BxDF.hlsli:198-212 */
+static int find_lobe(const float w[3], float rnd)
+{
+    float weight = 0.0f;
+    weight += w[2];
+    if (rnd < weight) return 2;
+    weight += w[1];
+    if (rnd < weight) return 1;
+    return 0;
+}
+
+/* Sample, BxDF.hlsli:214-226 and the three Sample* functions :81-86,110-118,148-170 */
+static int bsdf_sample(const bsdf_t *b, const surf_t *s, v3 V, const float w[3], const float rnd[4], v3 *L, int *lobe)
+{
+    *lobe = find_lobe(w, rnd[0]);
+    if (*lobe == LOBE_DIFFUSE) {
+        *L = rotate_vector_inverse(s->basis, cosine_ray(rnd[1], rnd[2]));
+        return v_dot(s->FrontNg, *L) > 0.0f;
+    }
+    v3 Vl = rotate_vector(s->basis, V);
+    v3 H = rotate_vector_inverse(s->basis, vndf_ray(rnd[1], rnd[2], b->Roughness, Vl));
+    if (*lobe == LOBE_SPECULAR) {
+        *L = reflect3(v_neg(V), H);
+        return v_dot(s->FrontNg, *L) > 0.0f;
+    }
+    float voh = f_abs(v_dot(V, H));
+    float eta = b->IORi / b->IORo;
+    if (eta * eta * (1.0f - voh * voh) > 1.0f || rnd[3] < oracle_fresnel_dielectric(eta, voh)) {
+        *L = reflect3(v_neg(V), H);
+    } else {
+        *L = refract3(v_neg(V), H, eta);
+        if (!f_finite(L->x) || !f_finite(L->y) || !f_finite(L->z)) *L = v_neg(V);
+    }
+    return 1;
+}
+
+/* ComputeHalfVector, BxDF.hlsli:228-245 */
+static v3 half_vector(const bsdf_t *b, const surf_t *s, v3 L, v3 V, int transmissive)
+{
+    v3 N = s->FrontNg;
+    v3 H;
+    if (transmissive && v_dot(N, L) < 0.0f) {
+        H = v_normalize(v_mad(b->IORo, L, v_scale(V, b->IORi)));
+        if (v_dot(N, H) < 0.0f) H = v_neg(H);
+    } else {
+        H = v_normalize(v_add(L, V));
+    }
+    return H;
+}
+
+/* EvaluatePDF(lobe) BxDF.hlsli:287-299 */
+static float bsdf_pdf(const bsdf_t *b, const surf_t *s, v3 L, v3 V, const float w[3], int lobe)
+{
+    v3 H = half_vector(b, s, L, V, w[LOBE_TRANSMISSION] > 0.0f);
+    float lw = w[lobe];
+    v3 N = s->Ns;
+    if (lobe == LOBE_DIFFUSE) {
+        if (v_dot(s->FrontNg, L) > 0.0f) { float nol = f_abs(v_dot(N, L)); return (nol * PT_INV_PI) * lw; }
+        return 0.0f * lw;
+    }
+    if (lobe == LOBE_SPECULAR) {
+        if (v_dot(s->FrontNg, L) > 0.0f) {
+            v3 Vl = rotate_vector(s->basis, V);
+            float vl[3] = { Vl.x, Vl.y, Vl.z };
+            float noh = f_abs(v_dot(N, H));
+            return oracle_vndf_pdf(vl, noh, b->Roughness) * lw;
+        }
+        return 0.0f * lw;
+    }
+    return f_abs(v_dot(N, L)) * lw;
+}
+
+/* Evaluate(lobe) BxDF.hlsli:301-315 */
+static v3 bsdf_eval(const bsdf_t *b, const surf_t *s, v3 L, v3 V, const float w[3], int lobe)
+{
+    float wt = w[LOBE_TRANSMISSION];
+    v3 H = half_vector(b, s, L, V, wt > 0.0f);
+    v3 N = s->Ns;
+    if (lobe == LOBE_TRANSMISSION) {
+        float nol = f_abs(v_dot(N, L));
+        return v_scale(v_scale(b->BaseColor, nol), wt);
+    }
+    float wr = 1.0f - wt;
+    if (!(v_dot(s->FrontNg, L) > 0.0f)) return v_scale(V3(0.0f, 0.0f, 0.0f), wr);
+    float nol = f_abs(v_dot(N, L)), nov = f_abs(v_dot(N, V)), voh = f_abs(v_dot(V, H));
+    if (lobe == LOBE_DIFFUSE) {
+        float dt = oracle_diffuse_term(b->Roughness, nol, nov, voh);
+        return v_scale(v_scale(v_scale(b->Albedo, nol), dt), wr);
+    }
+    float noh = f_abs(v_dot(N, H));
+    float D = oracle_distribution_term(b->Roughness, noh);
+    float G = oracle_geometry_term_mod(b->Roughness, nol, nov);
+    v3 F = fresnel_schlick(b->F0, voh);
+    float k = nol * D * G;
+    return v_scale(v_scale(F, k), wr);
+}
+
+void oracle_bsdf_step(const PtMaterial *m, int front, const float Ng_[3], const float V_[3],
+                      const float rnd[4], OracleBsdfOut *out)
+{
+    bsdf_t b; surf_t s;
+    v3 Ng = V3(Ng_[0], Ng_[1], Ng_[2]), V = V3(V_[0], V_[1], V_[2]);
+    bsdf_init(&b, V3(m->BaseColor[0], m->BaseColor[1], m->BaseColor[2]), m->Metallic, m->Roughness, m->IOR, m->Transmission, front);
+    surf_init(&s, front, Ng, front ? Ng : v_neg(Ng));
+    lobe_weights(&b, &s, V, out->weights);
+    v3 L = V3(0, 0, 0);
+    out->valid = bsdf_sample(&b, &s, V, out->weights, rnd, &L, &out->lobe);
+    out->L[0] = L.x; out->L[1] = L.y; out->L[2] = L.z;
+    out->pdf = 0.0f; out->f[0] = out->f[1] = out->f[2] = 0.0f;
+    if (out->valid) {
+        out->pdf = bsdf_pdf(&b, &s, L, V, out->weights, out->lobe);
+        v3 f = bsdf_eval(&b, &s, L, V, out->weights, out->lobe);
+        out->f[0] = f.x; out->f[1] = f.y; out->f[2] = f.z;
+    }
+}
+
+/* ------------------------------------------------------------------ the per-pixel loop */
+typedef struct {
+    float *events; uint32_t max_events, n_events;
+} trace_t;
+
+static void trace_event(trace_t *tr, uint32_t s, uint32_t bnc, const hit_t *h, int is_hit, v3 L, v3 T, uint32_t rng, int lobe, int flags)
+{
+    if (!tr || tr->n_events >= tr->max_events) return;
+    float *e = tr->events + 16 * (size_t)tr->n_events++;
+    e[0] = (float)s; e[1] = (float)bnc; e[2] = as_float(is_hit ? h->id : 0xFFFFFFFFu); e[3] = is_hit ? h->t : INFINITY;
+    e[4] = is_hit ? h->P.x : 0; e[5] = is_hit ? h->P.y : 0; e[6] = is_hit ? h->P.z : 0;
+    e[7] = L.x; e[8] = L.y; e[9] = L.z; e[10] = T.x; e[11] = T.y; e[12] = T.z;
+    e[13] = as_float(rng); e[14] = (float)lobe; e[15] = (float)flags;
+}
+
+/* Raytracing.hlsl:103-415 (DEFAULT permutation) + GBufferGeneration.hlsl:117-232 primary hit.
+ * Writes rgba; returns rays cast. */
+static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_t n,
+                             const PtSceneData *sd, const PtCamera *cam, const PtGraphicsSettings *gs,
+                             uint32_t px, uint32_t py, float rgba[4], uint64_t *paths_out, trace_t *tr)
+{
+    (void)paths_out;
+    uint64_t rays = 0;
+    uint32_t rng = oracle_rng_init(px, py, gs->FrameIndex); /* :108 */
+    v3 o, d; float tmin, tmax;
+    primary_ray(cam, px, py, gs->RenderSize[0], gs->RenderSize[1], &o, &d, &tmin, &tmax); /* :138 */
+
+    /* primary-hit pass (GBufferGeneration.hlsl:128-230) */
+    hit_t primary;
+    cast_ray(sph, n, o, d, tmin, tmax, &primary);
+    rays++;
+    if (!primary.hit) { /* miss: Radiance = env (GBufferGeneration.hlsl:223-227); bounce loop returns without writing (:249-252) */
+        v3 c = environment_color(sd, d);
+        rgba[0] = c.x; rgba[1] = c.y; rgba[2] = c.z; rgba[3] = 1.0f;
+        trace_event(tr, 0, 0, &primary, 0, V3(0, 0, 0), V3(1, 1, 1), rng, -1, 1);
+        return rays;
+    }
+    const PtMaterial *pm = &mat[primary.id];
+    v3 primary_radiance = v_scale(V3(pm->EmissiveColor[0], pm->EmissiveColor[1], pm->EmissiveColor[2]), pm->EmissiveStrength);
+    bsdf_t primary_bsdf;
+    bsdf_init(&primary_bsdf, V3(pm->BaseColor[0], pm->BaseColor[1], pm->BaseColor[2]), pm->Metallic, pm->Roughness, pm->IOR,
+              pm->Metallic < 1.0f ? pm->Transmission : 0.0f, primary.front); /* :143-150 */
+
+    v3 radiance = V3(0, 0, 0);
+    const uint32_t spp = gs->SamplesPerPixel;
+    for (uint32_t s = 0; s < spp; s++) { /* :191 */
+        v3 ro = o, rd = d;
+        int is_hit = 1;
+        hit_t hit = primary;
+        v3 emission = primary_radiance;
+        bsdf_t bsdf = primary_bsdf;
+        int lobe = -1;
+        v3 L = V3(0, 0, 0), T = V3(1, 1, 1);
+        v3 sample_radiance = V3(0, 0, 0);
+        for (uint32_t bnc = 0; bnc <= gs->Bounces; bnc++) { /* :213 */
+            if (bnc) { /* :219-234 */
+                ro = spawn_origin(hit.P, hit.N, hit.offset, L);
+                rd = L;
+                cast_ray(sph, n, ro, rd, 0.0f, INFINITY, &hit);
+                is_hit = hit.hit;
+                rays++;
+            }
+            if (!is_hit) { /* :242-259 (bnc > 0 here) */
+                v3 env = environment_color(sd, rd);
+                sample_radiance = v_add(sample_radiance, v_mul(T, env));
+                trace_event(tr, s, bnc, &hit, 0, L, T, rng, lobe, 2);
+                break;
+            }
+            if (bnc) { /* :293-305 */
+                const PtMaterial *m = &mat[hit.id];
+                emission = v_scale(V3(m->EmissiveColor[0], m->EmissiveColor[1], m->EmissiveColor[2]), m->EmissiveStrength);
+                bsdf_init(&bsdf, V3(m->BaseColor[0], m->BaseColor[1], m->BaseColor[2]), m->Metallic, m->Roughness, m->IOR, m->Transmission, hit.front);
+            }
+            sample_radiance = v_add(sample_radiance, v_mul(T, emission)); /* :320 */
+
+            surf_t sv;
+            surf_init(&sv, hit.front, hit.N, hit.shadingN); /* :323-324 */
+            v3 V = v_neg(rd);
+            float w[3];
+            lobe_weights(&bsdf, &sv, V, w); /* :329 */
+            float rnd[4];
+            rnd[0] = oracle_rng_float(&rng); rnd[1] = oracle_rng_float(&rng);
+            rnd[2] = oracle_rng_float(&rng); rnd[3] = oracle_rng_float(&rng); /* GetFloat4 :330 */
+            if (!bsdf_sample(&bsdf, &sv, V, w, rnd, &L, &lobe)) { trace_event(tr, s, bnc, &hit, 1, L, T, rng, lobe, 3); break; }
+            float pdf = bsdf_pdf(&bsdf, &sv, L, V, w, lobe); /* :335 */
+            if (pdf == 0.0f) { trace_event(tr, s, bnc, &hit, 1, L, T, rng, lobe, 4); break; }
+            v3 f = bsdf_eval(&bsdf, &sv, L, V, w, lobe); /* :341 */
+            if (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) { trace_event(tr, s, bnc, &hit, 1, L, T, rng, lobe, 5); break; }
+            T = v_mul(T, V3(f.x / pdf, f.y / pdf, f.z / pdf)); /* :346 */
+            if (gs->IsRussianRouletteEnabled && bnc > 3) { /* :348-356 */
+                float p = f_max(T.x, f_max(T.y, T.z));
+                if (oracle_rng_float(&rng) >= p) { trace_event(tr, s, bnc, &hit, 1, L, T, rng, lobe, 6); break; }
+                T = V3(T.x / p, T.y / p, T.z / p);
+            }
+            if (luminance(T) <= gs->ThroughputThreshold) { trace_event(tr, s, bnc, &hit, 1, L, T, rng, lobe, 7); break; } /* :361 */
+            trace_event(tr, s, bnc, &hit, 1, L, T, rng, lobe, 0);
+        }
+        radiance = v_add(radiance, sample_radiance); /* :373 */
+    }
+    if (f_finite(radiance.x) && f_finite(radiance.y) && f_finite(radiance.z)) { /* :378 */
+        float fs = (float)spp;
+        radiance = V3(radiance.x / fs, radiance.y / fs, radiance.z / fs);
+    } else {
+        radiance = V3(0, 0, 0);
+    }
+    rgba[0] = radiance.x; rgba[1] = radiance.y; rgba[2] = radiance.z; rgba[3] = 1.0f;
+    return rays;
+}
+
+typedef struct {
+    const PtSphere *sph; const PtMaterial *mat; uint32_t n;
+    const PtSceneData *sd; const PtCamera *cam; const PtGraphicsSettings *gs;
+    PtRect rect; uint32_t row_step; float *out;
+    int tid, nthreads;
+    uint64_t rays, paths;
+} job_t;
+
+static void *worker(void *arg)
+{
+    job_t *j = (job_t *)arg;
+    uint32_t k = 0;
+    for (uint32_t ry = 0; ry < j->rect.h; ry += j->row_step, k++) {
+        if ((int)(k % (uint32_t)j->nthreads) != j->tid) continue;
+        for (uint32_t rx = 0; rx < j->rect.w; rx++) {
+            float *px = j->out + 4 * ((size_t)ry * j->rect.w + rx);
+            j->rays += render_pixel(j->sph, j->mat, j->n, j->sd, j->cam, j->gs, j->rect.x + rx, j->rect.y + ry, px, &j->paths, NULL);
+            j->paths += j->gs->SamplesPerPixel; /* nominal (pixel, sample) pairs */
+        }
+    }
+    return NULL;
+}
+
+static int validate(const PtSceneData *sd, const PtGraphicsSettings *gs, uint32_t n)
+{
+    if (n == 0) return 1;
+    if (gs->RenderSize[0] == 0 || gs->RenderSize[1] == 0 || gs->SamplesPerPixel == 0) return 2;
+    if (gs->RenderSize[0] > 65535u || gs->RenderSize[1] > 65535u) return 2; /* (px<<16)|py seed */
+    if (gs->IsDIEnabled || gs->Denoiser) return 3;
+    if (sd->EnvironmentLightTextureDescriptor != 0xFFFFFFFFu) return 4;
+    return 0;
+}
+
+int oracle_render(const PtSphere *spheres, const PtMaterial *materials, uint32_t n,
+                  const PtSceneData *scene, const PtCamera *camera,
+                  const PtGraphicsSettings *gs, const PtRect *rect, uint32_t row_step,
+                  float *out_rgba, OracleStats *stats, int threads)
+{
+    int err = validate(scene, gs, n);
+    if (err) return err;
+    if (rect->x + rect->w > gs->RenderSize[0] || rect->y + rect->h > gs->RenderSize[1]) return 5;
+    if (row_step == 0) row_step = 1;
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    job_t *jobs = (job_t *)calloc((size_t)threads, sizeof(job_t));
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    for (int t = 0; t < threads; t++) {
+        job_t *j = &jobs[t];
+        j->sph = spheres; j->mat = materials; j->n = n; j->sd = scene; j->cam = camera; j->gs = gs;
+        j->rect = *rect; j->row_step = row_step; j->out = out_rgba; j->tid = t; j->nthreads = threads;
+    }
+    if (threads == 1) worker(&jobs[0]);
+    else {
+        for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, worker, &jobs[t]);
+        for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    }
+    if (stats) {
+        stats->rays = 0; stats->paths = 0;
+        for (int t = 0; t < threads; t++) { stats->rays += jobs[t].rays; stats->paths += jobs[t].paths; }
+    }
+    free(jobs); free(th);
+    return 0;
+}
+
+int oracle_trace_pixel(const PtSphere *spheres, const PtMaterial *materials, uint32_t n,
+                       const PtSceneData *scene, const PtCamera *camera,
+                       const PtGraphicsSettings *gs, uint32_t px, uint32_t py,
+                       float *events, uint32_t max_events, uint32_t *n_events)
+{
+    int err = validate(scene, gs, n);
+    if (err) return err;
+    trace_t tr = { events, max_events, 0 };
+    float rgba[4]; uint64_t paths = 0;
+    render_pixel(spheres, materials, n, scene, camera, gs, px, py, rgba, &paths, &tr);
+    *n_events = tr.n_events;
+    return 0;
+}

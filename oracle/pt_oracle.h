@@ -1,0 +1,93 @@
+/* pt_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Scalar plain-C restatement of the reference's per-pixel Monte-Carlo bounce loop
+ * (Shaders/Raytracing.hlsl:103-415, DEFAULT permutation, IsDIEnabled = 0,
+ * Denoiser::None) with the primary-hit pass (Shaders/GBufferGeneration.hlsl:117-232)
+ * folded in, over analytic spheres with BRUTE-FORCE O(N) intersection.
+ *
+ * PARITY UNPINNED: the reference has no tests/golden vectors and its
+ * arithmetic core (NVIDIA MathLib ml.hlsli) is an un-vendored submodule whose pinned
+ * commit is unknown.  MathLib functions are restated from SURVEY
+ * Appendix A (the build-frozen spec); see DESIGN.md "Frozen arithmetic spec".
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library.  The product (HIP) path never links or calls it.
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+
+#include "../include/pt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OracleStats {
+    uint64_t rays;   /* CastRay invocations incl. primaries */
+    uint64_t paths;  /* (pixel, sample) pairs started */
+} OracleStats;
+
+/* Render rect (w x h pixels, every row_step-th row of the rect is rendered, the others
+ * are left untouched) of the RenderSize image into out_rgba (rect.w*rect.h*4 floats,
+ * row-major inside the rect).  threads <= 1: single thread.  Returns 0 on success. */
+int oracle_render(const PtSphere *spheres, const PtMaterial *materials, uint32_t n,
+                  const PtSceneData *scene, const PtCamera *camera,
+                  const PtGraphicsSettings *gs, const PtRect *rect, uint32_t row_step,
+                  float *out_rgba, OracleStats *stats, int threads);
+
+/* Per-bounce trace of one pixel, for debugging parity: each event is 16 floats
+ * {sample, bounce, hit_id(as float bits), t, Px,Py,Pz, Lx,Ly,Lz, Tr,Tg,Tb, rng_state(bits), lobe, flags}. */
+int oracle_trace_pixel(const PtSphere *spheres, const PtMaterial *materials, uint32_t n,
+                       const PtSceneData *scene, const PtCamera *camera,
+                       const PtGraphicsSettings *gs, uint32_t px, uint32_t py,
+                       float *events, uint32_t max_events, uint32_t *n_events);
+
+/* ---- leaf functions exported for known-answer tests ---- */
+uint32_t oracle_hash(uint32_t x);
+uint32_t oracle_rng_init(uint32_t px, uint32_t py, uint32_t frame);
+uint32_t oracle_rng_next(uint32_t *state);            /* GetUint */
+float oracle_rng_float(uint32_t *state);               /* GetFloat, (0,1] */
+float oracle_halton(uint32_t index, uint32_t base);
+void oracle_sincos_2pi(float u, float *s, float *c);
+float oracle_log2(float x);
+float oracle_exp2(float x);
+float oracle_pow(float x, float y);
+float oracle_from_srgb(float c);
+void oracle_get_basis(const float n[3], float t[3], float b[3]);
+void oracle_cosine_ray(const float u[2], float out[3]);
+void oracle_vndf_ray(const float u[2], float roughness, const float vlocal[3], float out[3]);
+float oracle_vndf_pdf(const float vlocal[3], float noh, float roughness);
+float oracle_distribution_term(float roughness, float noh);
+float oracle_geometry_term_mod(float roughness, float nol, float nov);
+float oracle_fresnel_dielectric(float eta, float von);
+float oracle_diffuse_term(float roughness, float nol, float nov, float voh);
+void oracle_environment_term_rtg(const float f0[3], float nov, float roughness, float out[3]);
+void oracle_sky(const PtSceneData *scene, const float dir[3], float out[3]);
+/* returns 1 on hit and writes t */
+int oracle_intersect_sphere(const float o[3], const float d[3], float tmin, float tmax,
+                            const PtSphere *s, float *t);
+/* in: ray, t, sphere; out: P (re-projected), N (outward), offset, front */
+void oracle_hit_frame(const float o[3], const float d[3], float t, const PtSphere *s,
+                      float P[3], float N[3], float *offset, int *front);
+void oracle_spawn_origin(const float P[3], const float N[3], float offset, const float L[3], float out[3]);
+void oracle_primary_ray(const PtCamera *cam, uint32_t px, uint32_t py, uint32_t w, uint32_t h,
+                        float o[3], float d[3], float *tmin, float *tmax);
+
+/* One BSDF interaction (BxDF.hlsli): given material, front flag, outward normal N
+ * (geometric), view V and the 4 random numbers, compute lobe, L, pdf and f.
+ * returns 1 if a direction was sampled (Sample() returned true). */
+typedef struct OracleBsdfOut {
+    int lobe;
+    int valid;
+    float L[3];
+    float pdf;
+    float f[3];
+    float weights[3];
+} OracleBsdfOut;
+void oracle_bsdf_step(const PtMaterial *m, int front, const float Ng[3], const float V[3],
+                      const float rnd[4], OracleBsdfOut *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

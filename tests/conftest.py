@@ -1,0 +1,53 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_built():
+    """CPU-side native pieces (host mirror, oracle, host-compiled device headers) are built on demand; the HIP
+    library is built by __graft_entry__.build() (it travels to the GPU box prebuilt)."""
+    import __graft_entry__ as g
+
+    g.build_host()
+    g.build_oracle()
+    g.build_test_shim()
+    if not os.path.exists(os.path.join(g.PKG, "libpt_hip.so")):
+        g.build_hip()
+
+
+@pytest.fixture(scope="session")
+def dxrs():
+    import dxrs_amd_loader  # noqa: F401
+    import dxrs_amd
+
+    return dxrs_amd
+
+
+@pytest.fixture(scope="session")
+def host(dxrs):
+    return dxrs.load_host()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle.binding import load_oracle
+
+    return load_oracle()
+
+
+@pytest.fixture(scope="session")
+def renderer(dxrs):
+    """One GPU context shared by the gpu tests (single process, single context)."""
+    r = dxrs.Renderer(device=0)
+    yield r
+    r.close()

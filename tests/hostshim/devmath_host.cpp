@@ -1,0 +1,90 @@
+// devmath_host.cpp -- TEST SHIM: compiles the product's device leaf headers (csrc/pt_math.h,
+// csrc/pt_bsdf.h) as plain host C++ so tests can compare every leaf function bit-for-bit
+// with the CPU oracle without a GPU.  Not part of the product; never loaded by it.
+#include "../../directx-raytracing-spheres-demo_amd/csrc/pt_bsdf.h"
+
+using namespace pt;
+
+extern "C" {
+
+uint32_t dev_hash(uint32_t x) { return hash32(x); }
+uint32_t dev_rng_init(uint32_t px, uint32_t py, uint32_t frame) { return rng_init(px, py, frame); }
+uint32_t dev_rng_next(uint32_t* s) { return rng_next(*s); }
+float dev_rng_float(uint32_t* s) { return rng_float(*s); }
+void dev_sincos_2pi(float u, float* s, float* c) { sincos_2pi(u, *s, *c); }
+float dev_log2(float x) { return log2_spec(x); }
+float dev_exp2(float x) { return exp2_spec(x); }
+float dev_pow(float x, float y) { return pow_spec(x, y); }
+float dev_from_srgb(float c) { return from_srgb(c); }
+void dev_get_basis(const float n[3], float t[3], float b[3])
+{
+    Basis m = get_basis(make_f3(n[0], n[1], n[2]));
+    t[0] = m.T.x; t[1] = m.T.y; t[2] = m.T.z; b[0] = m.B.x; b[1] = m.B.y; b[2] = m.B.z;
+}
+void dev_cosine_ray(const float u[2], float out[3]) { f3 r = cosine_ray(u[0], u[1]); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void dev_vndf_ray(const float u[2], float roughness, const float vl[3], float out[3])
+{
+    f3 r = vndf_ray(u[0], u[1], roughness, make_f3(vl[0], vl[1], vl[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+float dev_vndf_pdf(const float vl[3], float noh, float roughness) { return vndf_pdf(make_f3(vl[0], vl[1], vl[2]), noh, roughness); }
+float dev_distribution_term(float roughness, float noh) { return distribution_term(roughness, noh); }
+float dev_geometry_term_mod(float roughness, float nol, float nov) { return geometry_term_mod(roughness, nol, nov); }
+float dev_fresnel_dielectric(float eta, float von) { return fresnel_dielectric(eta, von); }
+float dev_diffuse_term(float roughness, float nol, float nov, float voh) { return diffuse_term(roughness, nol, nov, voh); }
+void dev_environment_term_rtg(const float f0[3], float nov, float roughness, float out[3])
+{
+    f3 r = environment_term_rtg(make_f3(f0[0], f0[1], f0[2]), nov, roughness); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void dev_sky(const PtSceneData* sd, const float dir[3], float out[3])
+{
+    f3 c = environment_color(sd->EnvironmentLightColor[0], sd->EnvironmentLightColor[1], sd->EnvironmentLightColor[2],
+                             sd->EnvironmentLightColor[3], make_f3(dir[0], dir[1], dir[2]));
+    out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+int dev_intersect_sphere(const float o[3], const float d[3], float tmin, float tmax, const PtSphere* s, float* t)
+{
+    return intersect_sphere(make_f3(o[0], o[1], o[2]), make_f3(d[0], d[1], d[2]), tmin, tmax, make_f3(s->cx, s->cy, s->cz), s->r, *t) ? 1 : 0;
+}
+void dev_hit_frame(const float o[3], const float d[3], float t, const PtSphere* s, float P[3], float N[3], float* offset, int* front)
+{
+    HitFrame h = hit_frame(make_f3(o[0], o[1], o[2]), make_f3(d[0], d[1], d[2]), t, make_f3(s->cx, s->cy, s->cz), s->r);
+    P[0] = h.P.x; P[1] = h.P.y; P[2] = h.P.z; N[0] = h.N.x; N[1] = h.N.y; N[2] = h.N.z; *offset = h.offset; *front = h.front;
+}
+void dev_spawn_origin(const float P[3], const float N[3], float offset, const float L[3], float out[3])
+{
+    f3 r = spawn_origin(make_f3(P[0], P[1], P[2]), make_f3(N[0], N[1], N[2]), offset, make_f3(L[0], L[1], L[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void dev_primary_ray(const PtCamera* cam, uint32_t px, uint32_t py, uint32_t w, uint32_t h, float o[3], float d[3], float* tmin, float* tmax)
+{
+    f3 oo, dd;
+    primary_ray(camera_params(*cam), px, py, w, h, oo, dd, *tmin, *tmax);
+    o[0] = oo.x; o[1] = oo.y; o[2] = oo.z; d[0] = dd.x; d[1] = dd.y; d[2] = dd.z;
+}
+
+struct DevBsdfOut {
+    int lobe;
+    int valid;
+    float L[3];
+    float pdf;
+    float f[3];
+    float weights[3];
+};
+void dev_bsdf_step(const PtMaterial* m, int front, const float Ng_[3], const float V_[3], const float rnd[4], DevBsdfOut* out)
+{
+    f3 Ng = make_f3(Ng_[0], Ng_[1], Ng_[2]), V = make_f3(V_[0], V_[1], V_[2]);
+    Bsdf b = bsdf_init(make_f3(m->BaseColor[0], m->BaseColor[1], m->BaseColor[2]), m->Metallic, m->Roughness, m->IOR, m->Transmission, front != 0);
+    Surf s = surf_init(front != 0, Ng, front ? Ng : -Ng);
+    lobe_weights(b, s, V, out->weights);
+    f3 L = make_f3(0, 0, 0);
+    out->valid = bsdf_sample(b, s, V, out->weights, rnd, L, out->lobe) ? 1 : 0;
+    out->L[0] = L.x; out->L[1] = L.y; out->L[2] = L.z;
+    out->pdf = 0.0f; out->f[0] = out->f[1] = out->f[2] = 0.0f;
+    if (out->valid) {
+        out->pdf = bsdf_pdf(b, s, L, V, out->weights, out->lobe);
+        f3 f = bsdf_eval(b, s, L, V, out->weights, out->lobe);
+        out->f[0] = f.x; out->f[1] = f.y; out->f[2] = f.z;
+    }
+}
+
+}  // extern "C"
