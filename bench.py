@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the path-tracing hot path on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame: BASELINE.json configs[1] = demo default sphere scene (seed 0), 1920x1080, 1 spp, 8 bounces,
+Russian roulette on, sky-gradient environment, FrameIndex = step, camera jitter = Halton2D(step % 8 + 1) - 0.5.
+With N > 1 the frame is tile-partitioned (32x32 tiles, tile t -> rank t % N), every rank renders its tiles, the HDR
+tiles are gathered to rank 0 over RCCL and un-swizzled there (strong scaling: the frame is fixed).
+Inputs (scene, BVH) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, BOUNCES, SPP = 1920, 1080, 8, 1
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--bounces", type=int, default=BOUNCES)
+    ap.add_argument("--spp", type=int, default=SPP)
+    ap.add_argument("--scene", choices=["demo", "small", "procedural"], default="demo")
+    ap.add_argument("--spheres", type=int, default=1 << 20, help="sphere count of the procedural scene")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-row-step", type=int, default=4, help="the CPU baseline renders every n-th row of the frame")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import dxrs_amd_loader  # noqa: F401
+    import dxrs_amd
+    from dxrs_amd.types import graphics_settings
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    host = dxrs_amd.load_host()
+    kind = {"demo": dxrs_amd.host.SCENE_DEMO, "small": dxrs_amd.host.SCENE_SMALL, "procedural": dxrs_amd.host.SCENE_PROCEDURAL}[args.scene]
+    spheres, materials, sd = host.scene(kind, seed=1 if args.scene == "procedural" else 0, count=args.spheres)
+    w, h = args.width, args.height
+
+    stream = torch.cuda.current_stream(dev).cuda_stream  # kernels run on torch's stream so RCCL ops order after them
+    r = dxrs_amd.Renderer(device=local_rank, stream=stream)
+    accel = r.set_scene(spheres, materials, sd)
+    r.set_partition(rank, world)
+    gs = graphics_settings(w, h, frame_index=0, bounces=args.bounces, spp=args.spp)
+    r.set_constants(gs)
+    ts = 32
+    if world == 1:
+        frame = torch.empty((h * w, 4), dtype=torch.float32, device=dev)
+    else:
+        max_tiles = r.tiles_count(0)
+        packed = torch.zeros((max_tiles * ts * ts, 4), dtype=torch.float32, device=dev)
+        if rank == 0:
+            gathered = torch.empty((world, max_tiles * ts * ts, 4), dtype=torch.float32, device=dev)
+            gather_list = list(gathered.unbind(0))
+            frame = torch.empty((h * w, 4), dtype=torch.float32, device=dev)
+
+    cams = [host.camera(w, h, jitter_index=k, jitter_count=8) for k in range(8)]
+
+    def step(k):
+        gs.FrameIndex = k
+        r.set_camera(cams[k % 8])
+        r.set_constants(gs)
+        if world == 1:
+            r.render_device(frame.data_ptr())
+        else:
+            r.render_tiles(packed.data_ptr())
+            dist.gather(packed, gather_list if rank == 0 else None, dst=0)
+            if rank == 0:
+                r.unpack_tiles(gathered.data_ptr(), max_tiles, frame.data_ptr())
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        step(k)
+    r.totals(reset=True)
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    tot = r.totals(reset=True)
+    rays, paths = int(tot.rays), int(tot.paths)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([rays, paths], dtype=torch.int64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        rays, paths = int(c[0].item()), int(c[1].item())
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        result = {
+            "metric": f"Mrays/s (CastRay-equivalents incl. primaries) at {w}x{h}, {args.bounces} bounces, {args.spp} spp",
+            "value": rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "frames_per_s": args.steps / elapsed,
+            "mpaths_per_s": paths / elapsed / 1e6,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.scene} sphere scene (seed 0, {len(spheres)} spheres), {w}x{h}, {args.spp} spp, {args.bounces} bounces, RR on, sky env"
+                            + (f", 32x32 tiles interleaved over {world} GPUs + RCCL gather to rank 0" if world > 1 else ""),
+                "rays_per_frame": rays / args.steps,
+                "lbvh": {"nodes": int(accel.node_count), "depth": int(accel.depth), "lds_resident": bool(accel.lds_resident), "build_ms": float(accel.build_ms)},
+            },
+        }
+
+    # ---- roofline of the dominant kernel: per-launch HIP events on the render stream (rank 0's own tiles when N > 1)
+    if not args.no_roofline:
+        r.set_profiling(True)
+        n_prof = max(1, min(args.steps, 20))
+        agg = {"ms_trav": 0.0, "ms_shade": 0.0, "n_trav": 0, "n_shade": 0, "rays": 0, "slots": 0, "pixels": 0}
+        for k in range(n_prof):
+            gs.FrameIndex = args.warmup + k
+            r.set_camera(cams[(args.warmup + k) % 8])
+            r.set_constants(gs)
+            st = r.render_device(frame.data_ptr(), want_stats=True) if world == 1 else r.render_tiles(packed.data_ptr(), want_stats=True)
+            agg["ms_trav"] += st.ms_traverse
+            agg["ms_shade"] += st.ms_shade
+            agg["n_trav"] += st.traverse_launches
+            agg["n_shade"] += st.shade_launches
+            agg["rays"] += int(st.rays)
+            agg["pixels"] += int(st.pixels)
+        r.set_profiling(False)
+        if rank == 0:
+            slots = ((w + 7) // 8) * ((h + 7) // 8) * 64 * n_prof if world == 1 else r.tiles_count(0) * ts * ts * n_prof
+            secondary = agg["rays"] - agg["pixels"]
+            # DESIGN.md byte model.  traverse launches (incl. the primary launch): read o,d (32 B) + write hit (8 B) per
+            # secondary ray; the primary launch writes ray + hit (56 B) per slot.  shade launches: read ray + hit (56 B)
+            # per queue entry, write the next ray (48 B) per secondary ray, final store (16 B) per pixel.
+            bytes_trav = 40 * secondary + 56 * slots
+            bytes_shade = 56 * (slots + secondary) + 48 * secondary + 16 * agg["pixels"]
+            if agg["ms_trav"] >= agg["ms_shade"]:
+                name, b, ms, n = "traverse_kernel (+ primary_kernel)", bytes_trav, agg["ms_trav"], agg["n_trav"]
+            else:
+                name, b, ms, n = "shade_kernel", bytes_shade, agg["ms_shade"], agg["n_shade"]
+            achieved = (b / n) / (ms / n * 1e-3) / 1e9 if n and ms > 0 else 0.0
+            result["roofline"] = {
+                "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_launch": b / max(n, 1), "avg_launch_ms": ms / max(n, 1), "launches_per_frame": n / n_prof,
+                "traverse_ms_per_frame": agg["ms_trav"] / n_prof, "shade_ms_per_frame": agg["ms_shade"] / n_prof,
+            }
+
+    # ---- CPU baseline: the scalar oracle on this node's host cores, bounded sample of the same frame (rank 0, N = 1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.binding import load_oracle
+
+        oracle = load_oracle()
+        cores = min(os.cpu_count() or 1, 32)
+        gs.FrameIndex = args.warmup
+        t0c = time.perf_counter()
+        if args.scene == "procedural":
+            result["cpu_baseline"] = None  # brute-force oracle is O(N) per ray: not runnable at 2^20 spheres
+        else:
+            _, ost = oracle.render(spheres, materials, sd, cams[args.warmup % 8], gs, row_step=args.cpu_row_step, threads=cores)
+            dt = time.perf_counter() - t0c
+            result["cpu_baseline"] = {
+                "value": ost.rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                "sample": f"every {args.cpu_row_step}th row of the same {w}x{h} frame (FrameIndex {args.warmup}): {ost.rays} rays in {dt:.2f} s, "
+                          f"brute-force O(N) intersection over {len(spheres)} spheres, {cores} threads",
+            }
+
+    if rank == 0:
+        print(json.dumps(result))
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

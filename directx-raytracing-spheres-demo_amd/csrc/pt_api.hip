@@ -75,6 +75,8 @@ struct PtContext {
     uint32_t* h_counts = nullptr;  // pinned
     float4* d_out = nullptr;
     size_t cap_out = 0;
+    unsigned long long* d_totals = nullptr;  // [0] = secondary rays accumulated on the device
+    uint64_t tot_pixels = 0, tot_paths = 0, tot_slots = 0, tot_spp_paths = 0;  // host-known parts of the totals
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profiling = false;
@@ -245,6 +247,11 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         }
         PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, c->d_counts + k + 1, trav_grid, c->stream); }));
     }
+    PT_HIP(c, launch_accumulate_counts(c->d_counts, (uint32_t)iters_done, c->d_totals, c->stream));
+    c->tot_pixels += valid_pixels;
+    c->tot_paths += valid_pixels * spp;
+    c->tot_slots += pm.n_slots;
+    if (spp > 1) c->tot_spp_paths += valid_pixels * spp;
     if (timed) {
         PT_HIP(c, hipEventRecord(c->ev1, c->stream));
         PT_HIP(c, hipMemcpyAsync(c->h_counts, c->d_counts, (iters_done + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -316,6 +323,8 @@ PtStatus pt_create(const PtConfig* config, PtContext** out_ctx)
         c->own_stream = true;
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
+    if (hipMalloc(&c->d_totals, 2 * sizeof(unsigned long long)) != hipSuccess
+        || hipMemsetAsync(c->d_totals, 0, 2 * sizeof(unsigned long long), c->stream) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
     *out_ctx = c;
     return PT_OK;
 }
@@ -327,7 +336,7 @@ void pt_destroy(PtContext* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_queues(c);
     free_dev(c->d_sph); free_dev(c->d_mats); free_dev(c->d_nodes); free_dev(c->d_sph_sorted); free_dev(c->d_sorted_id);
-    free_dev(c->d_counts); free_dev(c->d_out);
+    free_dev(c->d_counts); free_dev(c->d_out); free_dev(c->d_totals);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->gpu_builder) lbvh_gpu_destroy(c->gpu_builder);
     for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -594,6 +603,26 @@ PtStatus pt_set_profiling(PtContext* c, int enabled)
 {
     if (!c) return PT_ERR_INVALID_ARG;
     c->profiling = enabled != 0;
+    return PT_OK;
+}
+
+PtStatus pt_get_totals(PtContext* c, PtStats* totals, int reset)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!totals) return fail(c, PT_ERR_INVALID_ARG, "pt_get_totals: null output");
+    PT_HIP(c, hipSetDevice(c->device));
+    unsigned long long secondary = 0;
+    PT_HIP(c, hipMemcpyAsync(&secondary, c->d_totals, sizeof secondary, hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    std::memset(totals, 0, sizeof *totals);
+    totals->rays = c->tot_pixels + secondary;
+    totals->paths = c->tot_paths;
+    totals->pixels = c->tot_pixels;
+    totals->bytes_algorithmic = 144ull * secondary + 112ull * c->tot_slots + 16ull * c->tot_pixels + 48ull * c->tot_spp_paths;
+    if (reset) {
+        PT_HIP(c, hipMemsetAsync(c->d_totals, 0, 2 * sizeof(unsigned long long), c->stream));
+        c->tot_pixels = c->tot_paths = c->tot_slots = c->tot_spp_paths = 0;
+    }
     return PT_OK;
 }
 

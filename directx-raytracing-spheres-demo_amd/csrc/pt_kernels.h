@@ -18,6 +18,7 @@ hipError_t launch_shade(const SceneView& sv, const PixelMap& pm, const FramePara
                         const Scratch& scratch, float4* out, const uint32_t* count_in, uint32_t* count_out, uint32_t grid, hipStream_t stream);
 hipError_t launch_trace(const SceneView& sv, const float* o, const float* d, uint32_t n_rays, float tmin, int use_bvh, float* out_t,
                         uint32_t* out_id, hipStream_t stream);
+hipError_t launch_accumulate_counts(const uint32_t* counts, uint32_t n_iters, unsigned long long* totals, hipStream_t stream);
 hipError_t launch_unpack_tiles(const float4* gathered, float4* frame, uint32_t w, uint32_t h, uint32_t ts, uint32_t tiles_x, uint32_t world,
                                uint32_t max_tiles, hipStream_t stream);
 

@@ -415,6 +415,15 @@ __global__ void unpack_tiles_kernel(const float4* __restrict__ gathered, float4*
     }
 }
 
+// totals[0] += sum of counts[1..n_iters] (secondary rays of this frame); one thread
+__global__ void accumulate_counts_kernel(const uint32_t* __restrict__ counts, uint32_t n_iters, unsigned long long* __restrict__ totals)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    unsigned long long s = 0;
+    for (uint32_t k = 1; k <= n_iters; k++) s += counts[k];
+    totals[0] += s;
+}
+
 // ------------------------------------------------------------------------------------------------ launch wrappers
 static uint32_t traverse_lds_bytes(const SceneView& sv, uint32_t stack_elem)
 {
@@ -476,6 +485,12 @@ hipError_t launch_trace(const SceneView& sv, const float* o, const float* d, uin
     } else {
         hipLaunchKernelGGL(brute_kernel, dim3(grid), dim3(kTraverseThreads), 0, stream, sv, o, d, n_rays, tmin, out_t, out_id);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_accumulate_counts(const uint32_t* counts, uint32_t n_iters, unsigned long long* totals, hipStream_t stream)
+{
+    hipLaunchKernelGGL(accumulate_counts_kernel, dim3(1), dim3(64), 0, stream, counts, n_iters, totals);
     return hipGetLastError();
 }
 

@@ -134,6 +134,9 @@ PtStatus pt_accel_download_order(PtContext *ctx, uint32_t *sorted_id, uint32_t c
 PtStatus pt_lbvh_build_host(const PtSphere *spheres, uint32_t n, PtBvhNode *nodes, uint32_t *sorted_id, uint32_t *depth);
 /* Turn per-kernel hipEvent profiling on/off (adds event records around every launch; disables the graph). */
 PtStatus pt_set_profiling(PtContext *ctx, int enabled);
+/* Running totals over every render call since the last reset, accumulated on the device without host
+ * synchronisation (rays, paths, pixels, bytes_algorithmic; the timing fields are zero).  Synchronises the stream. */
+PtStatus pt_get_totals(PtContext *ctx, PtStats *totals, int reset);
 PtStatus pt_synchronize(PtContext *ctx);
 
 const char *pt_last_error(PtContext *ctx);
