@@ -154,7 +154,7 @@ def main():
     if not args.no_roofline:
         r.set_profiling(True)
         n_prof = max(1, min(args.steps, 20))
-        agg = {"ms_trav": 0.0, "ms_shade": 0.0, "n_trav": 0, "n_shade": 0, "rays": 0, "slots": 0, "pixels": 0}
+        agg = {"ms_trav": 0.0, "ms_shade": 0.0, "ms_tail": 0.0, "n_trav": 0, "n_shade": 0, "n_tail": 0, "rays": 0, "slots": 0, "pixels": 0}
         for k in range(n_prof):
             gs.FrameIndex = args.warmup + k
             r.set_camera(cams[(args.warmup + k) % 8])
@@ -164,6 +164,8 @@ def main():
             agg["ms_shade"] += st.ms_shade
             agg["n_trav"] += st.traverse_launches
             agg["n_shade"] += st.shade_launches
+            agg["ms_tail"] += st.ms_tail
+            agg["n_tail"] += st.tail_launches
             agg["rays"] += int(st.rays)
             agg["pixels"] += int(st.pixels)
         r.set_profiling(False)
@@ -185,6 +187,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "bytes_per_launch": b / max(n, 1), "avg_launch_ms": ms / max(n, 1), "launches_per_frame": n / n_prof,
                 "traverse_ms_per_frame": agg["ms_trav"] / n_prof, "shade_ms_per_frame": agg["ms_shade"] / n_prof,
+                "tail_ms_per_frame": agg["ms_tail"] / n_prof,
             }
 
     # ---- CPU baseline: the scalar oracle on this node's host cores, bounded sample of the same frame (rank 0, N = 1)

@@ -73,6 +73,10 @@ struct PtContext {
     uint32_t* d_counts = nullptr;
     size_t cap_counts = 0;
     uint32_t* h_counts = nullptr;  // pinned
+    // queue sizes of a recent frame (pinned, written by an async copy, read without waiting): they only size the
+    // launch grids -- every kernel is a grid-stride loop, so a stale or missing estimate costs time, never correctness
+    uint32_t* h_prev_counts = nullptr;
+    uint64_t prev_signature = 0;
     float4* d_out = nullptr;
     size_t cap_out = 0;
     unsigned long long* d_totals = nullptr;  // [0] = secondary rays accumulated on the device
@@ -136,7 +140,12 @@ PtStatus ensure_buffers(PtContext* c, size_t n_slots, bool need_spp, size_t n_co
     if (n_counts > c->cap_counts) {
         free_dev(c->d_counts);
         if (c->h_counts) { (void)hipHostFree(c->h_counts); c->h_counts = nullptr; }
+        if (c->h_prev_counts) { (void)hipHostFree(c->h_prev_counts); c->h_prev_counts = nullptr; }
+        PT_HIP(c, hipHostMalloc(&c->h_prev_counts, n_counts * sizeof(uint32_t)));
+        std::memset(c->h_prev_counts, 0, n_counts * sizeof(uint32_t));
+        c->prev_signature = 0;
         PT_HIP(c, hipMalloc(&c->d_counts, n_counts * sizeof(uint32_t)));
+        PT_HIP(c, hipMemsetAsync(c->d_counts, 0, n_counts * sizeof(uint32_t), c->stream));
         PT_HIP(c, hipHostMalloc(&c->h_counts, n_counts * sizeof(uint32_t)));
         c->cap_counts = n_counts;
     }
@@ -199,28 +208,72 @@ EventPair* next_events(PtContext* c, int kind)
     return p;
 }
 
+// DESIGN.md byte model (what the wavefront formulation must move through HBM):
+//   secondary ray = 48 (shade writes the ray) + 32 + 8 (traverse reads o,d, writes the hit) + 56 (shade reads ray + hit) = 144 B
+//   primary slot  = 56 (primary writes ray + hit) + 56 (shade reads them) = 112 B;  pixel = 16 B final store
+//   spp > 1: radiance read-modify-write (32) per sample + primary-hit cache (8 write + 8 read) = 48 B per path
+uint64_t algorithmic_bytes(uint64_t secondary, uint64_t slots, uint64_t pixels, uint64_t spp_paths)
+{
+    return 144ull * secondary + 112ull * slots + 16ull * pixels + 48ull * spp_paths;
+}
+
+FrameCounters make_counters(const PtContext* c)
+{
+    FrameCounters fc{};
+    fc.counts = c->d_counts;
+    fc.n_counts = (uint32_t)c->cap_counts - 1u;  // the whole allocation is summed / zeroed every frame
+    fc.tail_rays = c->d_totals + 2;
+    fc.totals = c->d_totals;
+    return fc;
+}
+
 // The per-frame launch sequence.  out: device float4 buffer addressed by PixelRef::out_index.
+//
+//   primary -> shade(0) -> [traverse(k) -> shade(k)] for k = 1..S -> tail
+//
+// S wavefront bounces run as separate traverse / shade launches with stream compaction in between; after that the
+// queue is small and the fused tail kernel finishes every remaining path in one launch.  S = min(PT_TAIL_AFTER, ...)
+// for spp == 1; with spp > 1 (sample regeneration keeps the queue full) the host polls the queue size and switches to
+// the tail when it drops below PT_TAIL_THRESHOLD rays.
 PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, float4* out, PtStats* stats)
 {
     const uint32_t bounces = c->gs.Bounces, spp = c->gs.SamplesPerPixel;
-    const size_t max_iters = (size_t)spp * bounces + 1;  // shade passes; traverse passes = max_iters - 1
-    PtStatus st = ensure_buffers(c, pm.n_slots, spp > 1, max_iters + 2);
+    const size_t max_iters = (size_t)spp * bounces + 1;  // shade passes if everything ran as wavefront; traverse passes = max_iters - 1
+    const size_t wf_cap = spp > 1 ? max_iters : std::min<size_t>(max_iters, 64);
+    if (wf_cap + 2 > c->cap_counts && c->cap_counts) {
+        // growing the counter array: fold what the old one holds into the totals first
+        PT_HIP(c, launch_flush_counters(make_counters(c), c->stream));
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    PtStatus st = ensure_buffers(c, pm.n_slots, spp > 1, wf_cap + 2);
     if (st != PT_OK) return st;
 
     const SceneView sv = make_scene_view(c);
     const FrameParams fp = make_frame_params(c);
-    const uint32_t lds = traverse_lds_bytes_for(sv.n_nodes, sv.n, sv.stack_depth, c->lds_scene);
-    if (lds > kMaxLdsBytes) return fail(c, PT_ERR_UNSUPPORTED, "BVH depth needs more traversal-stack LDS than a workgroup can have");
+    const FrameCounters fc = make_counters(c);
+    if (traverse_lds_bytes_for(sv.n_nodes, sv.n, sv.stack_depth, c->lds_scene) > kMaxLdsBytes)
+        return fail(c, PT_ERR_UNSUPPORTED, "BVH depth needs more traversal-stack LDS than a workgroup can have");
 
-    const uint32_t trav_blocks = (pm.n_slots + kTraverseThreads - 1) / kTraverseThreads;
-    const uint32_t shade_blocks = (pm.n_slots + kShadeThreads - 1) / kShadeThreads;
-    const uint32_t trav_grid = std::max(1u, std::min(trav_blocks, c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", 8)));
-    const uint32_t shade_grid = std::max(1u, std::min(shade_blocks, c->num_cus * env_u32("PT_SHADE_BLOCKS_PER_CU", 16)));
+    // Launch grids: a kernel's queue size lives on the device; the host sizes the grid from the queue sizes an
+    // earlier frame of the same configuration had (1.25x margin), falling back to the n_slots upper bound.
+    const uint64_t signature = ((uint64_t)pm.n_slots << 32) ^ ((uint64_t)bounces << 20) ^ ((uint64_t)spp << 4) ^ pm.mode ^ ((uint64_t)c->n << 40);
+    const bool have_prev = spp == 1 && c->prev_signature == signature && c->h_prev_counts[0] == pm.n_slots && !std::getenv("PT_NO_ADAPTIVE_GRID");
+    auto estimate = [&](size_t k) -> uint32_t {
+        if (!have_prev || k >= c->cap_counts) return pm.n_slots;
+        const uint64_t e = (uint64_t)c->h_prev_counts[k] + c->h_prev_counts[k] / 4 + 64;
+        return (uint32_t)std::min<uint64_t>(e, pm.n_slots);
+    };
+    const uint32_t trav_cap = c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", 8);
+    const uint32_t shade_cap = c->num_cus * env_u32("PT_SHADE_BLOCKS_PER_CU", 16);
+    const uint32_t tail_cap = c->num_cus * env_u32("PT_TAIL_BLOCKS_PER_CU", 8);
+    auto grid_for = [](uint32_t items, uint32_t threads, uint32_t cap) { return std::max(1u, std::min((items + threads - 1) / threads, cap)); };
+    const uint32_t trav_grid = grid_for(pm.n_slots, kTraverseThreads, trav_cap);
+    const size_t tail_after = env_u32("PT_TAIL_AFTER", 2);           // wavefront bounces before the tail (spp == 1)
+    const uint32_t tail_threshold = env_u32("PT_TAIL_THRESHOLD", 262144);  // queue size below which spp > 1 switches to the tail
 
     const bool timed = stats != nullptr;
     c->ev_used = 0;
     if (timed) PT_HIP(c, hipEventRecord(c->ev0, c->stream));
-    PT_HIP(c, hipMemsetAsync(c->d_counts, 0, (max_iters + 2) * sizeof(uint32_t), c->stream));
 
     auto bracket = [&](int kind, auto&& launch) -> hipError_t {
         EventPair* ev = c->profiling ? next_events(c, kind) : nullptr;
@@ -230,52 +283,70 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         return e;
     };
 
-    PT_HIP(c, bracket(0, [&] { return launch_primary(sv, pm, fp, c->q[0], c->scratch, out, c->d_counts, trav_grid, c->stream); }));
+    PT_HIP(c, bracket(0, [&] { return launch_primary(sv, pm, fp, c->q[0], c->scratch, out, fc, trav_grid, c->stream); }));
 
-    size_t iters_done = 0;
-    for (size_t k = 0; k < max_iters; k++) {
+    // shade pass k consumes queue k (counts[k]) and appends to queue k+1; queue k+1 is then traversed, or handed to the tail
+    for (size_t k = 0;; k++) {
         const RayQueue& qin = c->q[k & 1];
         const RayQueue& qout = c->q[(k + 1) & 1];
-        PT_HIP(c, bracket(2, [&] { return launch_shade(sv, pm, fp, qin, qout, c->scratch, out, c->d_counts + k, c->d_counts + k + 1, shade_grid, c->stream); }));
-        iters_done = k + 1;
-        if (k + 1 == max_iters) break;
+        PT_HIP(c, bracket(2, [&] { return launch_shade(sv, pm, fp, qin, qout, c->scratch, out, c->d_counts + k, c->d_counts + k + 1, grid_for(estimate(k), kShadeThreads, shade_cap), c->stream); }));
+        if (k + 1 == max_iters) break;  // no path can have another ray
+        bool go_tail;
         if (spp > 1) {
-            // sample regeneration keeps the queue alive for a data-dependent number of passes: poll its size
-            PT_HIP(c, hipMemcpyAsync(c->h_counts + k + 1, c->d_counts + k + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            PT_HIP(c, hipMemcpyAsync(c->h_counts, c->d_counts + k + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             PT_HIP(c, hipStreamSynchronize(c->stream));
-            if (c->h_counts[k + 1] == 0) break;
+            if (c->h_counts[0] == 0) break;
+            go_tail = c->h_counts[0] < tail_threshold || k + 2 >= wf_cap;
+        } else {
+            go_tail = k >= tail_after || k + 2 >= wf_cap;
         }
-        PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, c->d_counts + k + 1, trav_grid, c->stream); }));
+        if (go_tail) {
+            PT_HIP(c, bracket(3, [&] { return launch_tail(sv, pm, fp, qout, c->scratch, out, c->d_counts + k + 1, fc.tail_rays, grid_for(estimate(k + 1), kTailThreads, tail_cap), c->stream); }));
+            break;
+        }
+        PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, c->d_counts + k + 1, grid_for(estimate(k + 1), kTraverseThreads, trav_cap), c->stream); }));
     }
-    PT_HIP(c, launch_accumulate_counts(c->d_counts, (uint32_t)iters_done, c->d_totals, c->stream));
+    if (spp == 1) {
+        // remember this frame's queue sizes for the next frame's grid sizing (no wait: see h_prev_counts)
+        PT_HIP(c, hipMemcpyAsync(c->h_prev_counts, c->d_counts, c->cap_counts * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        c->prev_signature = signature;
+    }
     c->tot_pixels += valid_pixels;
     c->tot_paths += valid_pixels * spp;
     c->tot_slots += pm.n_slots;
     if (spp > 1) c->tot_spp_paths += valid_pixels * spp;
     if (timed) {
         PT_HIP(c, hipEventRecord(c->ev1, c->stream));
-        PT_HIP(c, hipMemcpyAsync(c->h_counts, c->d_counts, (iters_done + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        // fold this frame's counters now so that its ray count can be read back
+        if (std::getenv("PT_DEBUG_COUNTS")) {
+            std::vector<uint32_t> hc(c->cap_counts);
+            PT_HIP(c, hipMemcpyAsync(hc.data(), c->d_counts, c->cap_counts * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            PT_HIP(c, hipStreamSynchronize(c->stream));
+            std::fprintf(stderr, "[pt] queue sizes:");
+            for (size_t k = 0; k < c->cap_counts && k < 20; k++) std::fprintf(stderr, " %u", hc[k]);
+            std::fprintf(stderr, "\n");
+        }
+        PT_HIP(c, launch_flush_counters(fc, c->stream));
+        unsigned long long secondary = 0;
+        PT_HIP(c, hipMemcpyAsync(&secondary, c->d_totals + 1, sizeof secondary, hipMemcpyDeviceToHost, c->stream));
         PT_HIP(c, hipStreamSynchronize(c->stream));
         std::memset(stats, 0, sizeof *stats);
         float ms = 0;
         PT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
         stats->ms_total = ms;
-        uint64_t secondary = 0;
-        for (size_t k = 1; k <= iters_done; k++) secondary += c->h_counts[k];
         stats->rays = valid_pixels + secondary;
         stats->pixels = valid_pixels;
         stats->paths = valid_pixels * spp;
-        // DESIGN.md byte model: secondary ray = 48 (shade write) + 32 + 8 (traverse) + 56 (shade read);
-        // primary slot = 56 (primary write) + 56 (shade read); pixel = 16 (final store);
-        // spp > 1 adds the radiance read-modify-write (32) per sample and the primary-hit cache (8 + 8).
-        stats->bytes_algorithmic = 144ull * secondary + 112ull * pm.n_slots + 16ull * valid_pixels
-                                   + (spp > 1 ? 48ull * valid_pixels * spp : 0ull);
+        stats->bytes_algorithmic = algorithmic_bytes(secondary, pm.n_slots, valid_pixels, spp > 1 ? valid_pixels * spp : 0);
         if (c->profiling) {
             for (size_t i = 0; i < c->ev_used; i++) {
                 float t = 0;
                 if (hipEventElapsedTime(&t, c->ev_pool[i].a, c->ev_pool[i].b) != hipSuccess) continue;
-                if (c->ev_pool[i].kind == 2) { stats->ms_shade += t; stats->shade_launches++; }
-                else { stats->ms_traverse += t; stats->traverse_launches++; }  // primary counts as a traverse launch
+                switch (c->ev_pool[i].kind) {
+                    case 2: stats->ms_shade += t; stats->shade_launches++; break;
+                    case 3: stats->ms_tail += t; stats->tail_launches++; break;
+                    default: stats->ms_traverse += t; stats->traverse_launches++; break;  // the primary launch counts as a traverse launch
+                }
             }
         }
     }
@@ -323,8 +394,8 @@ PtStatus pt_create(const PtConfig* config, PtContext** out_ctx)
         c->own_stream = true;
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
-    if (hipMalloc(&c->d_totals, 2 * sizeof(unsigned long long)) != hipSuccess
-        || hipMemsetAsync(c->d_totals, 0, 2 * sizeof(unsigned long long), c->stream) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
+    if (hipMalloc(&c->d_totals, 4 * sizeof(unsigned long long)) != hipSuccess
+        || hipMemsetAsync(c->d_totals, 0, 4 * sizeof(unsigned long long), c->stream) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
     *out_ctx = c;
     return PT_OK;
 }
@@ -338,6 +409,7 @@ void pt_destroy(PtContext* c)
     free_dev(c->d_sph); free_dev(c->d_mats); free_dev(c->d_nodes); free_dev(c->d_sph_sorted); free_dev(c->d_sorted_id);
     free_dev(c->d_counts); free_dev(c->d_out); free_dev(c->d_totals);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->h_prev_counts) (void)hipHostFree(c->h_prev_counts);
     if (c->gpu_builder) lbvh_gpu_destroy(c->gpu_builder);
     for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -612,13 +684,14 @@ PtStatus pt_get_totals(PtContext* c, PtStats* totals, int reset)
     if (!totals) return fail(c, PT_ERR_INVALID_ARG, "pt_get_totals: null output");
     PT_HIP(c, hipSetDevice(c->device));
     unsigned long long secondary = 0;
+    if (c->d_counts) PT_HIP(c, launch_flush_counters(make_counters(c), c->stream));  // fold the last frame in
     PT_HIP(c, hipMemcpyAsync(&secondary, c->d_totals, sizeof secondary, hipMemcpyDeviceToHost, c->stream));
     PT_HIP(c, hipStreamSynchronize(c->stream));
     std::memset(totals, 0, sizeof *totals);
     totals->rays = c->tot_pixels + secondary;
     totals->paths = c->tot_paths;
     totals->pixels = c->tot_pixels;
-    totals->bytes_algorithmic = 144ull * secondary + 112ull * c->tot_slots + 16ull * c->tot_pixels + 48ull * c->tot_spp_paths;
+    totals->bytes_algorithmic = algorithmic_bytes(secondary, c->tot_slots, c->tot_pixels, c->tot_spp_paths);
     if (reset) {
         PT_HIP(c, hipMemsetAsync(c->d_totals, 0, 2 * sizeof(unsigned long long), c->stream));
         c->tot_pixels = c->tot_paths = c->tot_slots = c->tot_spp_paths = 0;

@@ -96,6 +96,15 @@ struct FrameParams {
     float throughput_threshold;
 };
 
+// Per-frame device counters.  counts[k] = size of ray queue k (queue 0 = all slots); tail_rays = rays traced by the
+// fused tail kernel; totals[0] = running sum of secondary rays over finished frames, totals[1] = last finished frame.
+struct FrameCounters {
+    uint32_t* counts;
+    uint32_t n_counts;  // counts[0..n_counts] are valid
+    unsigned long long* tail_rays;
+    unsigned long long* totals;
+};
+
 // per-slot scratch (only touched when needed, see shade kernel)
 struct Scratch {
     float4* sample_rad;   // sampleRadiance of the sample in flight (valid when kFlagDirty)

@@ -7,18 +7,21 @@ namespace pt {
 
 constexpr uint32_t kTraverseThreads = 512;  // 8 waves share one LDS copy of the BVH
 constexpr uint32_t kShadeThreads = 256;
+constexpr uint32_t kTailThreads = 256;
 
 // dynamic LDS a traverse-type launch needs (scene copy if lds_scene, plus the per-lane stacks)
-uint32_t traverse_lds_bytes_for(uint32_t n_nodes, uint32_t n, uint32_t depth, bool lds_scene);
+uint32_t traverse_lds_bytes_for(uint32_t n_nodes, uint32_t n, uint32_t depth, bool lds_scene, uint32_t threads = kTraverseThreads);
 
 hipError_t launch_primary(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& q, const Scratch& scratch,
-                          float4* out, uint32_t* count0, uint32_t grid, hipStream_t stream);
+                          float4* out, const FrameCounters& fc, uint32_t grid, hipStream_t stream);
 hipError_t launch_traverse(const SceneView& sv, const RayQueue& q, const uint32_t* count_ptr, uint32_t grid, hipStream_t stream);
 hipError_t launch_shade(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const RayQueue& qout,
                         const Scratch& scratch, float4* out, const uint32_t* count_in, uint32_t* count_out, uint32_t grid, hipStream_t stream);
 hipError_t launch_trace(const SceneView& sv, const float* o, const float* d, uint32_t n_rays, float tmin, int use_bvh, float* out_t,
                         uint32_t* out_id, hipStream_t stream);
-hipError_t launch_accumulate_counts(const uint32_t* counts, uint32_t n_iters, unsigned long long* totals, hipStream_t stream);
+hipError_t launch_tail(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const Scratch& scratch, float4* out,
+                       const uint32_t* count_ptr, unsigned long long* tail_rays, uint32_t grid, hipStream_t stream);
+hipError_t launch_flush_counters(const FrameCounters& fc, hipStream_t stream);
 hipError_t launch_unpack_tiles(const float4* gathered, float4* frame, uint32_t w, uint32_t h, uint32_t ts, uint32_t tiles_x, uint32_t world,
                                uint32_t max_tiles, hipStream_t stream);
 

@@ -21,6 +21,29 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// Called by every thread of ONE block.  totals[0] += secondary rays of the frame that just finished
+// (tail counter + queue sizes 1..n); then tail = 0, counts[0] = n_slots, counts[1..n] = 0.
+__device__ __forceinline__ void frame_counters_begin(const FrameCounters& fc, uint32_t n_slots)
+{
+    __shared__ unsigned long long s_sum[16];
+    unsigned long long s = 0;
+    for (uint32_t k = 1 + threadIdx.x; k <= fc.n_counts; k += blockDim.x) s += fc.counts[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63u) == 0) s_sum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = *fc.tail_rays;
+        for (uint32_t w = 0; w < (blockDim.x + 63u) / 64u; w++) t += s_sum[w];
+        fc.totals[0] += t;
+        fc.totals[1] = t;  // secondary rays of the last finished frame
+        *fc.tail_rays = 0ull;
+        fc.counts[0] = n_slots;
+    }
+    __syncthreads();
+    for (uint32_t k = 1 + threadIdx.x; k <= fc.n_counts; k += blockDim.x) fc.counts[k] = 0u;
+}
+
 // Stage the BVH (nodes, Morton-ordered spheres, ids) into LDS.  Layout: [nodes | spheres | ids].
 __device__ __forceinline__ void stage_scene(const SceneView& sv, float4* lds)
 {
@@ -34,9 +57,21 @@ __device__ __forceinline__ void stage_scene(const SceneView& sv, float4* lds)
 
 __host__ __device__ inline uint32_t scene_lds_bytes(uint32_t n_nodes, uint32_t n) { return (n_nodes * 4u + n) * 16u + ((n * 4u + 15u) & ~15u); }
 
-// Closest hit over the LBVH.  nodes/sph/ids may live in LDS or global memory (address space is inferred after
-// inlining).  stack: per-lane stack, entry e of lane l at stack[e * stride + l].
-// Result is identical to brute force: nearest t, ties -> lowest original id (boxes are padded, culling is <=).
+// Stack entries hold a child reference: internal node index i >= 0, or leaf (Morton-sorted sphere index k) as ~k.
+// The 16-bit stack (trees with < 32768 leaves) stores a leaf as 0x8000 | k.
+template <typename StackT> __device__ __forceinline__ StackT stack_encode(int c);
+template <> __device__ __forceinline__ uint16_t stack_encode<uint16_t>(int c) { return c < 0 ? (uint16_t)(0x8000u | (uint32_t)~c) : (uint16_t)c; }
+template <> __device__ __forceinline__ uint32_t stack_encode<uint32_t>(int c) { return (uint32_t)c; }
+__device__ __forceinline__ int stack_decode(uint16_t v) { return (v & 0x8000u) ? ~(int)(v & 0x7FFFu) : (int)v; }
+__device__ __forceinline__ int stack_decode(uint32_t v) { return (int)v; }
+
+constexpr int kTraversalDone = (int)0x80000000;  // not a valid leaf code (leaf codes are >= -2^30)
+
+// Closest hit over the LBVH ("while-while" traversal: descend internal nodes until every lane of the wave holds a
+// leaf or has finished, then run the sphere tests together).  nodes/sph/ids may live in LDS or global memory (the
+// address space is inferred after inlining).  stack: per-lane stack, entry e of lane l at stack[e * stride + l].
+// The result is identical to brute force: nearest t, ties -> lowest original id (leaf boxes are padded so the slab
+// test is conservative w.r.t. intersect_sphere; culling is <=).
 template <typename StackT>
 __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, const float4* __restrict__ sph,
                                             const uint32_t* __restrict__ ids, uint32_t n, f3 o, f3 d, float tmin, float tmax,
@@ -56,58 +91,54 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
     int node = 0;
     uint32_t sp = 0;
     for (;;) {
-        const float4 n0 = nodes[node * 4 + 0];
-        const float4 n1 = nodes[node * 4 + 1];
-        const float4 n2 = nodes[node * 4 + 2];
-        const float4 n3 = nodes[node * 4 + 3];
-        // child 0: lo = (n0.x,n0.y,n0.z) hi = (n0.w,n1.x,n1.y); child 1: lo = (n1.z,n1.w,n2.x) hi = (n2.y,n2.z,n2.w)
-        float ax = pt_fma(n0.x, ix, ox), bx = pt_fma(n0.w, ix, ox);
-        float ay = pt_fma(n0.y, iy, oy), by = pt_fma(n1.x, iy, oy);
-        float az = pt_fma(n0.z, iz, oz), bz = pt_fma(n1.y, iz, oz);
-        float tn0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-        float tf0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
-        ax = pt_fma(n1.z, ix, ox); bx = pt_fma(n2.y, ix, ox);
-        ay = pt_fma(n1.w, iy, oy); by = pt_fma(n2.z, iy, oy);
-        az = pt_fma(n2.x, iz, oz); bz = pt_fma(n2.w, iz, oz);
-        float tn1 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-        float tf1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
-        bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-        const int c0 = __builtin_bit_cast(int, n3.x), c1 = __builtin_bit_cast(int, n3.y);
-        if (h0 && c0 < 0) {
-            const uint32_t k = ~(uint32_t)c0;
+        while (node >= 0) {
+            const float4 n0 = nodes[node * 4 + 0];
+            const float4 n1 = nodes[node * 4 + 1];
+            const float4 n2 = nodes[node * 4 + 2];
+            const float4 n3 = nodes[node * 4 + 3];
+            // child 0: lo = (n0.x,n0.y,n0.z) hi = (n0.w,n1.x,n1.y); child 1: lo = (n1.z,n1.w,n2.x) hi = (n2.y,n2.z,n2.w)
+            float ax = pt_fma(n0.x, ix, ox), bx = pt_fma(n0.w, ix, ox);
+            float ay = pt_fma(n0.y, iy, oy), by = pt_fma(n1.x, iy, oy);
+            float az = pt_fma(n0.z, iz, oz), bz = pt_fma(n1.y, iz, oz);
+            const float tn0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+            const float tf0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
+            ax = pt_fma(n1.z, ix, ox); bx = pt_fma(n2.y, ix, ox);
+            ay = pt_fma(n1.w, iy, oy); by = pt_fma(n2.z, iy, oy);
+            az = pt_fma(n2.x, iz, oz); bz = pt_fma(n2.w, iz, oz);
+            const float tn1 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+            const float tf1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
+            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+            const int c0 = __builtin_bit_cast(int, n3.x), c1 = __builtin_bit_cast(int, n3.y);
+            if (h0 && h1) {
+                const bool swap = tn1 < tn0;
+                const int near_c = swap ? c1 : c0, far_c = swap ? c0 : c1;
+                stack[sp * stride] = stack_encode<StackT>(far_c);
+                sp++;
+                node = near_c;
+            } else if (h0) {
+                node = c0;
+            } else if (h1) {
+                node = c1;
+            } else if (sp == 0) {
+                node = kTraversalDone;
+            } else {
+                sp--;
+                node = stack_decode(stack[sp * stride]);
+            }
+        }
+        if (node == kTraversalDone) break;
+        {
+            const uint32_t k = ~(uint32_t)node;
             const float4 s = sph[k];
             float t;
             if (intersect_sphere(o, d, tmin, kInf, make_f3(s.x, s.y, s.z), s.w, t)) {
                 const uint32_t id = ids[k];
                 if (t < best || (t == best && best_id != kMissId && id < best_id)) { best = t; best_id = id; }
             }
-            h0 = false;
         }
-        if (h1 && c1 < 0) {
-            const uint32_t k = ~(uint32_t)c1;
-            const float4 s = sph[k];
-            float t;
-            if (intersect_sphere(o, d, tmin, kInf, make_f3(s.x, s.y, s.z), s.w, t)) {
-                const uint32_t id = ids[k];
-                if (t < best || (t == best && best_id != kMissId && id < best_id)) { best = t; best_id = id; }
-            }
-            h1 = false;
-        }
-        if (h0 && h1) {
-            const bool swap = tn1 < tn0;
-            const int near_c = swap ? c1 : c0, far_c = swap ? c0 : c1;
-            stack[sp * stride] = (StackT)far_c;
-            sp++;
-            node = near_c;
-        } else if (h0) {
-            node = c0;
-        } else if (h1) {
-            node = c1;
-        } else {
-            if (sp == 0) break;
-            sp--;
-            node = (int)stack[sp * stride];
-        }
+        if (sp == 0) break;
+        sp--;
+        node = stack_decode(stack[sp * stride]);
     }
     // t < tmax is required by intersect_sphere's contract: best starts at tmax and only shrinks
     t_out = best; id_out = best_id;
@@ -116,9 +147,11 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
 // ------------------------------------------------------------------------------------------------ primary
 template <bool kLds, typename StackT>
 __global__ __launch_bounds__(kTraverseThreads) void primary_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue q,
-                                                                   Scratch scratch, float4* __restrict__ out, uint32_t* __restrict__ count0)
+                                                                   Scratch scratch, float4* __restrict__ out, FrameCounters fc)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count0 = pm.n_slots;  // queue 0 holds every slot
+    // Counter housekeeping rides on the first block (everything later in the frame is stream-ordered after this kernel):
+    // fold the previous frame's ray counts into the running total, then reset the per-frame counters.
+    if (blockIdx.x == 0) frame_counters_begin(fc, pm.n_slots);
     extern __shared__ float4 smem[];
     const float4* nodes = sv.nodes;
     const float4* sph = sv.sph_sorted;
@@ -193,6 +226,148 @@ __global__ __launch_bounds__(kTraverseThreads) void traverse_kernel(SceneView sv
 // ------------------------------------------------------------------------------------------------ shade
 __device__ __forceinline__ f3 load3(const float4& v) { return make_f3(v.x, v.y, v.z); }
 
+// Per-path state carried between kernels in the ray queue (48 B) -- see RayQueue in pt_device.h.
+struct PathState {
+    f3 o, d, T;
+    uint32_t slot, rng, bounce, sample;
+    bool dirty;  // scratch.sample_rad[slot] holds this sample's radiance so far
+};
+
+// One iteration of the bounce-loop body (Raytracing.hlsl:213-364) for a path whose ray (ps.o, ps.d) has been traced to
+// (t, id); on sample end it accumulates into the pixel, and either finishes the pixel or regenerates the next sample
+// from the cached primary hit and keeps going.  Returns true when ps holds a new ray that must be traced.
+__device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const Scratch& scratch,
+                                           float4* __restrict__ out, PathState& ps, float t, uint32_t id)
+{
+    const uint32_t slot = ps.slot;
+    const PixelRef pr = slot_to_pixel(pm, slot);
+    for (;;) {
+        // sampleRadiance so far is (dirty ? scratch : 0); srad_loaded says whether `srad` holds it
+        f3 srad = make_f3(0.f, 0.f, 0.f);
+        bool srad_loaded = false, srad_changed = false;
+        bool end_sample = false;
+        f3 L = make_f3(0.f, 0.f, 0.f);
+        HitFrame hf;
+        if (id == kMissId) {
+            const f3 env = environment_color(sv.env[0], sv.env[1], sv.env[2], sv.env[3], ps.d);
+            if (ps.bounce == 0) {  // primary miss: pixel = environment (GBufferGeneration.hlsl:223-227; Raytracing.hlsl:249-252)
+                out[pr.out_index] = make_float4(env.x, env.y, env.z, 1.0f);
+                return false;
+            }
+            if (ps.dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
+            srad_loaded = true;
+            srad = srad + ps.T * env;  // :254
+            end_sample = true;
+        } else {
+            const float4 sp = sv.sph[id];
+            const float4 m0 = sv.mats[id * 4 + 0], m1 = sv.mats[id * 4 + 1], m2 = sv.mats[id * 4 + 2];
+            hf = hit_frame(ps.o, ps.d, t, load3(sp), sp.w);
+            const f3 emission = make_f3(m1.y, m1.z, m1.w) * m1.x;  // Material::GetEmission
+            // bounce 0 mirrors the G-buffer round trip: Transmission = Metallic < 1 ? Transmission : 0 (Raytracing.hlsl:148)
+            const float transmission = (ps.bounce == 0 && !(m2.x < 1.0f)) ? 0.0f : m2.w;
+            const Bsdf bsdf = bsdf_init(load3(m0), m2.x, m2.y, m2.z, transmission, hf.front);
+            const bool t_finite = is_finite(ps.T.x) && is_finite(ps.T.y) && is_finite(ps.T.z);
+            if (emission.x != 0.0f || emission.y != 0.0f || emission.z != 0.0f || !t_finite) {
+                if (ps.dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
+                srad_loaded = true;
+                srad = srad + ps.T * emission;  // :320
+                srad_changed = true;
+            }
+            const bool last = ps.bounce == fp.bounces;
+            if (last && ps.sample + 1 == fp.spp) {
+                end_sample = true;  // the sample drawn on the final iteration is never used and no later sample reads the RNG
+            } else {
+                const f3 Ns = hf.front ? hf.N : -hf.N;  // HitInfo.hlsli:60-64
+                const Surf surf = surf_init(hf.front, hf.N, Ns);
+                const f3 V = -ps.d;
+                float w[3];
+                lobe_weights(bsdf, surf, V, w);
+                float rnd[4];
+                rnd[0] = rng_float(ps.rng); rnd[1] = rng_float(ps.rng); rnd[2] = rng_float(ps.rng); rnd[3] = rng_float(ps.rng);  // :330
+                int lobe;
+                if (!bsdf_sample(bsdf, surf, V, w, rnd, L, lobe)) {
+                    end_sample = true;
+                } else {
+                    const float pdf = bsdf_pdf(bsdf, surf, L, V, w, lobe);
+                    if (pdf == 0.0f) {
+                        end_sample = true;
+                    } else {
+                        const f3 f = bsdf_eval(bsdf, surf, L, V, w, lobe);
+                        if (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) {
+                            end_sample = true;
+                        } else {
+                            ps.T = ps.T * make_f3(f.x / pdf, f.y / pdf, f.z / pdf);  // :346
+                            if (fp.rr_enabled && ps.bounce > 3) {                     // :348-356
+                                const float p = pt_max(ps.T.x, pt_max(ps.T.y, ps.T.z));
+                                if (rng_float(ps.rng) >= p) end_sample = true;
+                                else ps.T = make_f3(ps.T.x / p, ps.T.y / p, ps.T.z / p);
+                            }
+                            if (!end_sample && luminance(ps.T) <= fp.throughput_threshold) end_sample = true;  // :361
+                            if (last) end_sample = true;
+                        }
+                    }
+                }
+            }
+        }
+        if (!end_sample) {
+            // spawn the next ray (Raytracing.hlsl:219-224)
+            ps.o = spawn_origin(hf.P, hf.N, hf.offset, L);
+            ps.d = L;
+            ps.bounce++;
+            if (srad_changed) { scratch.sample_rad[slot] = make_float4(srad.x, srad.y, srad.z, 0.f); ps.dirty = true; }
+            return true;
+        }
+        // ---- end of sample: radiance += sampleRadiance (:373)
+        if (!srad_loaded) {
+            if (ps.dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
+        }
+        f3 acc = make_f3(0.f, 0.f, 0.f);
+        if (ps.sample > 0) { const float4 r = scratch.radiance[slot]; acc = load3(r); }
+        const f3 total = acc + srad;
+        ps.sample++;
+        if (ps.sample == fp.spp) {  // :378-385
+            f3 res = make_f3(0.f, 0.f, 0.f);
+            if (is_finite(total.x) && is_finite(total.y) && is_finite(total.z)) {
+                const float fs = (float)fp.spp;
+                res = make_f3(total.x / fs, total.y / fs, total.z / fs);
+            }
+            out[pr.out_index] = make_float4(res.x, res.y, res.z, 1.0f);
+            return false;
+        }
+        scratch.radiance[slot] = make_float4(total.x, total.y, total.z, 0.f);
+        // ---- regenerate: every sample restarts from the same primary ray / primary hit (:193-198)
+        float tmin, tmax;
+        primary_ray(fp.cam, pr.px, pr.py, pm.img_w, pm.img_h, ps.o, ps.d, tmin, tmax);
+        const uint2 ph = scratch.primary_hit[slot];
+        t = as_float(ph.x);
+        id = ph.y;
+        ps.T = make_f3(1.f, 1.f, 1.f);
+        ps.bounce = 0;
+        ps.dirty = false;
+    }
+}
+
+__device__ __forceinline__ PathState load_path(const RayQueue& q, uint32_t i)
+{
+    const float4 a = q.q0[i], b = q.q1[i], c = q.q2[i];
+    PathState ps;
+    ps.o = load3(a); ps.d = load3(b); ps.T = load3(c);
+    ps.slot = as_uint(a.w); ps.rng = as_uint(b.w);
+    const uint32_t flags = as_uint(c.w);
+    ps.bounce = flags & kFlagBounceMask;
+    ps.sample = (flags >> kFlagSampleShift) & kFlagSampleMask;
+    ps.dirty = (flags & kFlagDirty) != 0;
+    return ps;
+}
+
+__device__ __forceinline__ void store_path(const RayQueue& q, uint32_t j, const PathState& ps)
+{
+    const uint32_t flags = (ps.bounce & kFlagBounceMask) | ((ps.sample & kFlagSampleMask) << kFlagSampleShift) | (ps.dirty ? kFlagDirty : 0u);
+    q.q0[j] = make_float4(ps.o.x, ps.o.y, ps.o.z, as_float(ps.slot));
+    q.q1[j] = make_float4(ps.d.x, ps.d.y, ps.d.z, as_float(ps.rng));
+    q.q2[j] = make_float4(ps.T.x, ps.T.y, ps.T.z, as_float(flags));
+}
+
 __global__ __launch_bounds__(kShadeThreads) void shade_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue qin, RayQueue qout,
                                                               Scratch scratch, float4* __restrict__ out,
                                                               const uint32_t* __restrict__ count_in_ptr, uint32_t* __restrict__ count_out_ptr)
@@ -205,132 +380,11 @@ __global__ __launch_bounds__(kShadeThreads) void shade_kernel(SceneView sv, Pixe
     for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
         const uint32_t i = base + threadIdx.x;
         bool emit = false;
-        f3 o, d, T;
-        uint32_t slot = 0, rng = 0, flags = 0;
+        PathState ps;
         if (i < count) {
-            const float4 a = qin.q0[i], b = qin.q1[i], c = qin.q2[i];
+            ps = load_path(qin, i);
             const uint2 h = qin.hit[i];
-            o = load3(a); d = load3(b); T = load3(c);
-            slot = as_uint(a.w); rng = as_uint(b.w); flags = as_uint(c.w);
-            float t = as_float(h.x);
-            uint32_t id = h.y;
-            uint32_t bounce = flags & kFlagBounceMask;
-            uint32_t sample = (flags >> kFlagSampleShift) & kFlagSampleMask;
-            bool dirty = (flags & kFlagDirty) != 0;
-            if (bounce != 0xFFu) {
-                const PixelRef pr = slot_to_pixel(pm, slot);
-                for (;;) {
-                    // ---- one iteration of the bounce loop body, Raytracing.hlsl:213-364
-                    f3 srad = make_f3(0.f, 0.f, 0.f);  // sampleRadiance so far is (dirty ? scratch : 0); srad_loaded says whether `srad` holds it
-                    bool srad_loaded = false, srad_changed = false;
-                    bool end_sample = false;
-                    f3 L = make_f3(0.f, 0.f, 0.f);
-                    HitFrame hf;
-                    if (id == kMissId) {
-                        const f3 env = environment_color(sv.env[0], sv.env[1], sv.env[2], sv.env[3], d);
-                        if (bounce == 0) {  // primary miss: pixel = environment (GBufferGeneration.hlsl:223-227; Raytracing.hlsl:249-252)
-                            out[pr.out_index] = make_float4(env.x, env.y, env.z, 1.0f);
-                            break;
-                        }
-                        if (dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
-                        srad_loaded = true;
-                        srad = srad + T * env;  // :254
-                        end_sample = true;
-                    } else {
-                        const float4 sp = sv.sph[id];
-                        const float4 m0 = sv.mats[id * 4 + 0], m1 = sv.mats[id * 4 + 1], m2 = sv.mats[id * 4 + 2];
-                        hf = hit_frame(o, d, t, load3(sp), sp.w);
-                        const f3 emission = make_f3(m1.y, m1.z, m1.w) * m1.x;  // Material::GetEmission
-                        // bounce 0 mirrors the G-buffer round trip: Transmission = Metallic < 1 ? Transmission : 0 (Raytracing.hlsl:148)
-                        const float transmission = (bounce == 0 && !(m2.x < 1.0f)) ? 0.0f : m2.w;
-                        const Bsdf bsdf = bsdf_init(load3(m0), m2.x, m2.y, m2.z, transmission, hf.front);
-                        const bool t_finite = is_finite(T.x) && is_finite(T.y) && is_finite(T.z);
-                        if (emission.x != 0.0f || emission.y != 0.0f || emission.z != 0.0f || !t_finite) {
-                            if (dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
-                            srad_loaded = true;
-                            srad = srad + T * emission;  // :320
-                            srad_changed = true;
-                        }
-                        const bool last = bounce == fp.bounces;
-                        if (last && sample + 1 == fp.spp) {
-                            end_sample = true;  // the sample drawn on the final iteration is never used and no later sample reads the RNG
-                        } else {
-                            const f3 Ns = hf.front ? hf.N : -hf.N;  // HitInfo.hlsli:60-64
-                            const Surf surf = surf_init(hf.front, hf.N, Ns);
-                            const f3 V = -d;
-                            float w[3];
-                            lobe_weights(bsdf, surf, V, w);
-                            float rnd[4];
-                            rnd[0] = rng_float(rng); rnd[1] = rng_float(rng); rnd[2] = rng_float(rng); rnd[3] = rng_float(rng);  // :330
-                            int lobe;
-                            if (!bsdf_sample(bsdf, surf, V, w, rnd, L, lobe)) {
-                                end_sample = true;
-                            } else {
-                                const float pdf = bsdf_pdf(bsdf, surf, L, V, w, lobe);
-                                if (pdf == 0.0f) {
-                                    end_sample = true;
-                                } else {
-                                    const f3 f = bsdf_eval(bsdf, surf, L, V, w, lobe);
-                                    if (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) {
-                                        end_sample = true;
-                                    } else {
-                                        T = T * make_f3(f.x / pdf, f.y / pdf, f.z / pdf);  // :346
-                                        if (fp.rr_enabled && bounce > 3) {                  // :348-356
-                                            const float p = pt_max(T.x, pt_max(T.y, T.z));
-                                            if (rng_float(rng) >= p) end_sample = true;
-                                            else T = make_f3(T.x / p, T.y / p, T.z / p);
-                                        }
-                                        if (!end_sample && luminance(T) <= fp.throughput_threshold) end_sample = true;  // :361
-                                        if (last) end_sample = true;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    if (!end_sample) {
-                        // spawn the next ray (Raytracing.hlsl:219-224)
-                        o = spawn_origin(hf.P, hf.N, hf.offset, L);
-                        d = L;
-                        bounce++;
-                        if (srad_changed) { scratch.sample_rad[slot] = make_float4(srad.x, srad.y, srad.z, 0.f); dirty = true; }
-                        emit = true;
-                        break;
-                    }
-                    // ---- end of sample: radiance += sampleRadiance (:373)
-                    if (!srad_loaded) {
-                        if (dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
-                    }
-                    f3 total = srad;
-                    if (fp.spp > 1) {
-                        f3 acc = make_f3(0.f, 0.f, 0.f);
-                        if (sample > 0) { const float4 r = scratch.radiance[slot]; acc = load3(r); }
-                        total = acc + srad;
-                    } else {
-                        total = make_f3(0.f, 0.f, 0.f) + srad;
-                    }
-                    sample++;
-                    if (sample == fp.spp) {  // :378-385
-                        f3 res = make_f3(0.f, 0.f, 0.f);
-                        if (is_finite(total.x) && is_finite(total.y) && is_finite(total.z)) {
-                            const float fs = (float)fp.spp;
-                            res = make_f3(total.x / fs, total.y / fs, total.z / fs);
-                        }
-                        out[pr.out_index] = make_float4(res.x, res.y, res.z, 1.0f);
-                        break;
-                    }
-                    scratch.radiance[slot] = make_float4(total.x, total.y, total.z, 0.f);
-                    // ---- regenerate: every sample restarts from the same primary ray / primary hit (:193-198)
-                    float tmin, tmax;
-                    primary_ray(fp.cam, pr.px, pr.py, pm.img_w, pm.img_h, o, d, tmin, tmax);
-                    const uint2 ph = scratch.primary_hit[slot];
-                    t = as_float(ph.x);
-                    id = ph.y;
-                    T = make_f3(1.f, 1.f, 1.f);
-                    bounce = 0;
-                    dirty = false;
-                }
-            }
-            flags = (bounce & kFlagBounceMask) | ((sample & kFlagSampleMask) << kFlagSampleShift) | (dirty ? kFlagDirty : 0u);
+            if (ps.bounce != 0xFFu) emit = shade_step(sv, pm, fp, scratch, out, ps, as_float(h.x), h.y);
         }
         // ---- wave64 ballot + prefix compaction into the next queue; one atomic per block
         const unsigned long long mask = __ballot(emit);
@@ -345,14 +399,54 @@ __global__ __launch_bounds__(kShadeThreads) void shade_kernel(SceneView sv, Pixe
             s_block_base = total ? atomicAdd(count_out_ptr, total) : 0u;
         }
         __syncthreads();
-        if (emit) {
-            const uint32_t j = s_block_base + s_wave_count[wave] + prefix;
-            qout.q0[j] = make_float4(o.x, o.y, o.z, as_float(slot));
-            qout.q1[j] = make_float4(d.x, d.y, d.z, as_float(rng));
-            qout.q2[j] = make_float4(T.x, T.y, T.z, as_float(flags));
-        }
+        if (emit) store_path(qout, s_block_base + s_wave_count[wave] + prefix, ps);
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------------ fused tail
+// When the queue has become small, per-launch latency (dispatch + BVH staging + one traversal chain) dominates a
+// wavefront pass.  The tail kernel finishes every queued path in ONE launch: each lane alternates closest_hit and
+// shade_step in registers until its pixel is done (persistent threads; no queue traffic, no compaction).
+template <bool kLds, typename StackT>
+__global__ __launch_bounds__(kTailThreads) void tail_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue qin, Scratch scratch,
+                                                            float4* __restrict__ out, const uint32_t* __restrict__ count_ptr,
+                                                            unsigned long long* __restrict__ tail_rays)
+{
+    extern __shared__ float4 smem[];
+    const uint32_t count = *count_ptr;
+    if (blockIdx.x * blockDim.x >= count) return;
+    const float4* nodes = sv.nodes;
+    const float4* sph = sv.sph_sorted;
+    const uint32_t* ids = sv.sorted_id;
+    StackT* stack;
+    if (kLds) {
+        stage_scene(sv, smem);
+        nodes = smem;
+        sph = smem + sv.n_nodes * 4u;
+        ids = reinterpret_cast<const uint32_t*>(smem + sv.n_nodes * 4u + sv.n);
+        stack = reinterpret_cast<StackT*>(reinterpret_cast<char*>(smem) + scene_lds_bytes(sv.n_nodes, sv.n));
+    } else {
+        stack = reinterpret_cast<StackT*>(smem);
+    }
+    stack += threadIdx.x;
+    uint32_t my_rays = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        PathState ps = load_path(qin, i);
+        if (ps.bounce == 0xFFu) continue;
+        for (;;) {
+            float t;
+            uint32_t id;
+            closest_hit<StackT>(nodes, sph, ids, sv.n, ps.o, ps.d, 0.0f, kInf, stack, blockDim.x, t, id);
+            if (!shade_step(sv, pm, fp, scratch, out, ps, t, id)) break;
+            my_rays++;  // rays spawned inside the tail (the input queue's rays are already in counts[])
+        }
+    }
+    // wave-reduce the ray count, one atomic per wave
+    unsigned long long total = my_rays;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
+    if (lane_id() == 0 && total) atomicAdd(tail_rays, total);
 }
 
 // ------------------------------------------------------------------------------------------------ test hooks
@@ -416,12 +510,10 @@ __global__ void unpack_tiles_kernel(const float4* __restrict__ gathered, float4*
 }
 
 // totals[0] += sum of counts[1..n_iters] (secondary rays of this frame); one thread
-__global__ void accumulate_counts_kernel(const uint32_t* __restrict__ counts, uint32_t n_iters, unsigned long long* __restrict__ totals)
+// Fold the last frame's counters into the running total (pt_get_totals / stats); leaves the counters zeroed.
+__global__ void flush_counters_kernel(FrameCounters fc)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    unsigned long long s = 0;
-    for (uint32_t k = 1; k <= n_iters; k++) s += counts[k];
-    totals[0] += s;
+    if (blockIdx.x == 0) frame_counters_begin(fc, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------ launch wrappers
@@ -431,15 +523,15 @@ static uint32_t traverse_lds_bytes(const SceneView& sv, uint32_t stack_elem)
     return (sv.lds_scene ? scene_lds_bytes(sv.n_nodes, sv.n) : 0u) + stack;
 }
 
-uint32_t traverse_lds_bytes_for(uint32_t n_nodes, uint32_t n, uint32_t depth, bool lds_scene)
+uint32_t traverse_lds_bytes_for(uint32_t n_nodes, uint32_t n, uint32_t depth, bool lds_scene, uint32_t threads)
 {
-    const uint32_t elem = n_nodes < 65536u ? 2u : 4u;
-    return (lds_scene ? scene_lds_bytes(n_nodes, n) : 0u) + kTraverseThreads * depth * elem;
+    const uint32_t elem = n_nodes < 32767u ? 2u : 4u;
+    return (lds_scene ? scene_lds_bytes(n_nodes, n) : 0u) + threads * depth * elem;
 }
 
 #define PT_DISPATCH_TRAVERSE(KERNEL, GRID, STREAM, ...)                                                        \
     do {                                                                                                        \
-        const bool small = sv.n_nodes < 65536u;                                                                 \
+        const bool small = sv.n_nodes < 32767u;                                                                 \
         const uint32_t lds = traverse_lds_bytes(sv, small ? 2u : 4u);                                           \
         if (lds > 65536u) {                                                                                     \
             const void* fn = sv.lds_scene ? (small ? (const void*)KERNEL<true, uint16_t> : (const void*)KERNEL<true, uint32_t>)   \
@@ -456,15 +548,32 @@ uint32_t traverse_lds_bytes_for(uint32_t n_nodes, uint32_t n, uint32_t depth, bo
     } while (0)
 
 hipError_t launch_primary(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& q, const Scratch& scratch,
-                          float4* out, uint32_t* count0, uint32_t grid, hipStream_t stream)
+                          float4* out, const FrameCounters& fc, uint32_t grid, hipStream_t stream)
 {
-    PT_DISPATCH_TRAVERSE(primary_kernel, grid, stream, sv, pm, fp, q, scratch, out, count0);
+    PT_DISPATCH_TRAVERSE(primary_kernel, grid, stream, sv, pm, fp, q, scratch, out, fc);
     return hipGetLastError();
 }
 
 hipError_t launch_traverse(const SceneView& sv, const RayQueue& q, const uint32_t* count_ptr, uint32_t grid, hipStream_t stream)
 {
     PT_DISPATCH_TRAVERSE(traverse_kernel, grid, stream, sv, q, count_ptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_tail(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const Scratch& scratch, float4* out,
+                       const uint32_t* count_ptr, unsigned long long* tail_rays, uint32_t grid, hipStream_t stream)
+{
+    const bool small = sv.n_nodes < 32767u;
+    const uint32_t elem = small ? 2u : 4u;
+    const uint32_t lds = (sv.lds_scene ? scene_lds_bytes(sv.n_nodes, sv.n) : 0u) + kTailThreads * sv.stack_depth * elem;
+#define PT_TAIL(L, T)                                                                                                      \
+    do {                                                                                                                    \
+        if (lds > 65536u) (void)hipFuncSetAttribute((const void*)tail_kernel<L, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((tail_kernel<L, T>), dim3(grid), dim3(kTailThreads), lds, stream, sv, pm, fp, qin, scratch, out, count_ptr, tail_rays); \
+    } while (0)
+    if (sv.lds_scene) { if (small) PT_TAIL(true, uint16_t); else PT_TAIL(true, uint32_t); }
+    else { if (small) PT_TAIL(false, uint16_t); else PT_TAIL(false, uint32_t); }
+#undef PT_TAIL
     return hipGetLastError();
 }
 
@@ -488,9 +597,9 @@ hipError_t launch_trace(const SceneView& sv, const float* o, const float* d, uin
     return hipGetLastError();
 }
 
-hipError_t launch_accumulate_counts(const uint32_t* counts, uint32_t n_iters, unsigned long long* totals, hipStream_t stream)
+hipError_t launch_flush_counters(const FrameCounters& fc, hipStream_t stream)
 {
-    hipLaunchKernelGGL(accumulate_counts_kernel, dim3(1), dim3(64), 0, stream, counts, n_iters, totals);
+    hipLaunchKernelGGL(flush_counters_kernel, dim3(1), dim3(256), 0, stream, fc);
     return hipGetLastError();
 }
 

@@ -79,6 +79,9 @@ typedef struct PtStats {
     uint32_t traverse_launches;
     uint32_t shade_launches;
     uint64_t bytes_algorithmic; /* DESIGN.md byte model: per-ray queue traffic + per-path accumulate/store */
+    double ms_tail;             /* device time of the fused tail launch (0 unless profiling on) */
+    uint32_t tail_launches;
+    uint32_t _reserved;
 } PtStats;
 
 /* BVH node as traversed on the device (DESIGN.md "LBVH layout"); exposed for structural tests. */

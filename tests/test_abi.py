@@ -1,0 +1,112 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/pt_api.h declares; argument validation
+that needs no device works; nothing in the product imports the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "directx-raytracing-spheres-demo_amd")
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pt_api.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(dxrs):
+    lib = dxrs.load_hip().lib
+    syms = declared_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(lib, s), f"libpt_hip.so does not export {s}"
+    assert sorted(dxrs.binding.API_SYMBOLS) == syms  # the Python binding covers the whole header
+    assert b"gfx950" in lib.pt_version()
+
+
+def test_create_without_device_fails_loudly(dxrs):
+    """No CPU fallback: without a GPU pt_create returns PT_ERR_NO_DEVICE and Renderer raises."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = dxrs.load_hip().lib
+    cfg = dxrs.PtConfig(device=0)
+    ctx = C.c_void_p()
+    assert lib.pt_create(C.byref(cfg), C.byref(ctx)) == 2 and not ctx.value
+    with pytest.raises(dxrs.PtError):
+        dxrs.Renderer()
+    assert lib.pt_create(None, C.byref(ctx)) == 1  # PT_ERR_INVALID_ARG
+
+
+def test_null_context_is_rejected(dxrs):
+    lib = dxrs.load_hip().lib
+    assert lib.pt_set_camera(None, None) == 1 and lib.pt_render(None, None, None, 0, None) == 1
+    assert lib.pt_tiles_count(None, 0) == 0
+    assert lib.pt_last_error(None) == b"null context"
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: no product source may reference oracle/ (SURVEY 8c / task rule 3)."""
+    offenders = []
+    for base, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", "Makefile")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"#include[^\n]*oracle|from\s+oracle|import\s+oracle|oracle/|libpt_oracle|pt_oracle\.", text):
+                    offenders.append(os.path.join(base, f))
+    assert not offenders, offenders
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(PKG, "libpt_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+def test_host_lbvh_structure(dxrs, host):
+    """LBVH structural invariants on the host builder, for the three scene families."""
+    lib = dxrs.load_hip()
+    for kind, count in ((dxrs.host.SCENE_SMALL, 0), (dxrs.host.SCENE_DEMO, 0), (dxrs.host.SCENE_PROCEDURAL, 20000)):
+        spheres, _, _ = host.scene(kind, seed=1, count=count)
+        nodes, order, depth = lib.lbvh_build_host(spheres)
+        check_lbvh(spheres, nodes, order, depth)
+    # degenerate inputs: duplicates and a single sphere
+    one = np.zeros(1, dtype=dxrs.SPHERE_DTYPE); one["r"] = 1
+    nodes, order, depth = lib.lbvh_build_host(one)
+    assert len(nodes) == 0 and list(order) == [0] and depth == 0
+    dup = np.zeros(64, dtype=dxrs.SPHERE_DTYPE); dup["r"] = 0.5; dup["cx"] = 1.0
+    nodes, order, depth = lib.lbvh_build_host(dup)
+    check_lbvh(dup, nodes, order, depth)
+
+
+def check_lbvh(spheres, nodes, order, depth):
+    n = len(spheres)
+    assert len(nodes) == n - 1 and sorted(order) == list(range(n))  # every sphere in exactly one leaf slot
+    seen_leaf = np.zeros(n, dtype=int)
+    seen_node = np.zeros(n - 1, dtype=int)
+    cx, cy, cz, r = (spheres[k].astype(np.float64) for k in ("cx", "cy", "cz", "r"))
+    lo = np.stack([cx - r, cy - r, cz - r], 1); hi = np.stack([cx + r, cy + r, cz + r], 1)
+    box_lo = np.zeros((n - 1, 3)); box_hi = np.zeros((n - 1, 3))
+    # iterative post-order
+    stack, post, maxdepth = [(0, 1)], [], 0
+    while stack:
+        i, d = stack.pop(); post.append(i); maxdepth = max(maxdepth, d); seen_node[i] += 1
+        for c in (nodes[i]["child0"], nodes[i]["child1"]):
+            if c >= 0:
+                assert nodes[c]["parent"] == i
+                stack.append((int(c), d + 1))
+            else:
+                seen_leaf[~c] += 1
+    assert (seen_leaf == 1).all() and (seen_node == 1).all() and nodes[0]["parent"] == -1
+    assert maxdepth == depth
+    for i in reversed(post):
+        for ck, lk, hk in (("child0", "lo0", "hi0"), ("child1", "lo1", "hi1")):
+            c = nodes[i][ck]
+            if c < 0:
+                sid = order[~c]
+                assert (nodes[i][lk] <= lo[sid]).all() and (nodes[i][hk] >= hi[sid]).all()  # padded leaf box contains the sphere
+                assert (lo[sid] - nodes[i][lk]).max() < 1e-3 * max(1.0, np.abs(lo).max())   # ... tightly
+            else:
+                assert (nodes[i][lk] <= box_lo[c]).all() and (nodes[i][hk] >= box_hi[c]).all()  # parent box contains children
+        box_lo[i] = np.minimum(nodes[i]["lo0"], nodes[i]["lo1"]); box_hi[i] = np.maximum(nodes[i]["hi0"], nodes[i]["hi1"])
+    assert (box_lo[0] <= lo.min(0)).all() and (box_hi[0] >= hi.max(0)).all()
