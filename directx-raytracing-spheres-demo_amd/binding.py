@@ -97,8 +97,19 @@ _hip = None
 
 
 def load_hip():
+    """Load libpt_hip.so once.  If torch is already imported, let it initialise its (bundled) ROCm runtime first:
+    loading /opt/rocm's runtime before torch's makes torch report "No HIP GPUs are available" later."""
     global _hip
     if _hip is None:
+        import sys
+
+        torch = sys.modules.get("torch")
+        if torch is not None:
+            try:
+                if torch.cuda.is_available():
+                    torch.cuda.init()
+            except Exception:
+                pass
         _hip = HipLib()
     return _hip
 

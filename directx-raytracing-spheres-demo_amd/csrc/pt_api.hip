@@ -267,7 +267,8 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     const uint32_t shade_cap = c->num_cus * env_u32("PT_SHADE_BLOCKS_PER_CU", 16);
     const uint32_t tail_cap = c->num_cus * env_u32("PT_TAIL_BLOCKS_PER_CU", 8);
     auto grid_for = [](uint32_t items, uint32_t threads, uint32_t cap) { return std::max(1u, std::min((items + threads - 1) / threads, cap)); };
-    const uint32_t trav_grid = grid_for(pm.n_slots, kTraverseThreads, trav_cap);
+    const uint32_t trav_threads = traverse_threads(c->lds_scene);
+    const uint32_t trav_grid = grid_for(pm.n_slots, trav_threads, trav_cap);
     const size_t tail_after = env_u32("PT_TAIL_AFTER", 2);           // wavefront bounces before the tail (spp == 1)
     const uint32_t tail_threshold = env_u32("PT_TAIL_THRESHOLD", 262144);  // queue size below which spp > 1 switches to the tail
 
@@ -304,7 +305,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
             PT_HIP(c, bracket(3, [&] { return launch_tail(sv, pm, fp, qout, c->scratch, out, c->d_counts + k + 1, fc.tail_rays, grid_for(estimate(k + 1), kTailThreads, tail_cap), c->stream); }));
             break;
         }
-        PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, c->d_counts + k + 1, grid_for(estimate(k + 1), kTraverseThreads, trav_cap), c->stream); }));
+        PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, c->d_counts + k + 1, grid_for(estimate(k + 1), trav_threads, trav_cap), c->stream); }));
     }
     if (spp == 1) {
         // remember this frame's queue sizes for the next frame's grid sizing (no wait: see h_prev_counts)

@@ -5,12 +5,15 @@
 
 namespace pt {
 
-constexpr uint32_t kTraverseThreads = 512;  // 8 waves share one LDS copy of the BVH
+constexpr uint32_t kTraverseThreads = 512;  // launch bound; 8 waves share one LDS copy of the BVH
+// threads per traverse-type workgroup: 512 when the BVH is staged in LDS (amortises the copy), 256 when it is read
+// from global memory (the per-lane stacks are then the only LDS use, and smaller groups keep more waves resident)
+inline uint32_t traverse_threads(bool lds_scene) { return lds_scene ? kTraverseThreads : 256u; }
 constexpr uint32_t kShadeThreads = 256;
 constexpr uint32_t kTailThreads = 256;
 
 // dynamic LDS a traverse-type launch needs (scene copy if lds_scene, plus the per-lane stacks)
-uint32_t traverse_lds_bytes_for(uint32_t n_nodes, uint32_t n, uint32_t depth, bool lds_scene, uint32_t threads = kTraverseThreads);
+uint32_t traverse_lds_bytes_for(uint32_t n_nodes, uint32_t n, uint32_t depth, bool lds_scene, uint32_t threads = 0);
 
 hipError_t launch_primary(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& q, const Scratch& scratch,
                           float4* out, const FrameCounters& fc, uint32_t grid, hipStream_t stream);

@@ -519,13 +519,14 @@ __global__ void flush_counters_kernel(FrameCounters fc)
 // ------------------------------------------------------------------------------------------------ launch wrappers
 static uint32_t traverse_lds_bytes(const SceneView& sv, uint32_t stack_elem)
 {
-    const uint32_t stack = kTraverseThreads * sv.stack_depth * stack_elem;
+    const uint32_t stack = traverse_threads(sv.lds_scene != 0) * sv.stack_depth * stack_elem;
     return (sv.lds_scene ? scene_lds_bytes(sv.n_nodes, sv.n) : 0u) + stack;
 }
 
 uint32_t traverse_lds_bytes_for(uint32_t n_nodes, uint32_t n, uint32_t depth, bool lds_scene, uint32_t threads)
 {
     const uint32_t elem = n_nodes < 32767u ? 2u : 4u;
+    if (threads == 0) threads = traverse_threads(lds_scene);
     return (lds_scene ? scene_lds_bytes(n_nodes, n) : 0u) + threads * depth * elem;
 }
 
@@ -539,11 +540,11 @@ uint32_t traverse_lds_bytes_for(uint32_t n_nodes, uint32_t n, uint32_t depth, bo
             (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
         }                                                                                                       \
         if (sv.lds_scene) {                                                                                     \
-            if (small) hipLaunchKernelGGL((KERNEL<true, uint16_t>), dim3(GRID), dim3(kTraverseThreads), lds, STREAM, __VA_ARGS__); \
-            else hipLaunchKernelGGL((KERNEL<true, uint32_t>), dim3(GRID), dim3(kTraverseThreads), lds, STREAM, __VA_ARGS__);       \
+            if (small) hipLaunchKernelGGL((KERNEL<true, uint16_t>), dim3(GRID), dim3(traverse_threads(true)), lds, STREAM, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<true, uint32_t>), dim3(GRID), dim3(traverse_threads(true)), lds, STREAM, __VA_ARGS__);       \
         } else {                                                                                                \
-            if (small) hipLaunchKernelGGL((KERNEL<false, uint16_t>), dim3(GRID), dim3(kTraverseThreads), lds, STREAM, __VA_ARGS__); \
-            else hipLaunchKernelGGL((KERNEL<false, uint32_t>), dim3(GRID), dim3(kTraverseThreads), lds, STREAM, __VA_ARGS__);       \
+            if (small) hipLaunchKernelGGL((KERNEL<false, uint16_t>), dim3(GRID), dim3(traverse_threads(false)), lds, STREAM, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<false, uint32_t>), dim3(GRID), dim3(traverse_threads(false)), lds, STREAM, __VA_ARGS__);       \
         }                                                                                                       \
     } while (0)
 
@@ -587,7 +588,8 @@ hipError_t launch_shade(const SceneView& sv, const PixelMap& pm, const FramePara
 hipError_t launch_trace(const SceneView& sv, const float* o, const float* d, uint32_t n_rays, float tmin, int use_bvh, float* out_t,
                         uint32_t* out_id, hipStream_t stream)
 {
-    const uint32_t grid = (n_rays + kTraverseThreads - 1) / kTraverseThreads < 2048u ? (n_rays + kTraverseThreads - 1) / kTraverseThreads : 2048u;
+    const uint32_t tt = traverse_threads(sv.lds_scene != 0);
+    const uint32_t grid = (n_rays + tt - 1) / tt < 2048u ? (n_rays + tt - 1) / tt : 2048u;
     if (grid == 0) return hipSuccess;
     if (use_bvh) {
         PT_DISPATCH_TRAVERSE(trace_kernel, grid, stream, sv, o, d, n_rays, tmin, out_t, out_id);

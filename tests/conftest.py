@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    # torch bundles its own ROCm runtime: it has to initialise BEFORE libpt_hip.so pulls in /opt/rocm's, otherwise
+    # torch later reports "No HIP GPUs are available" (the tile tests use torch tensors as device buffers).
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -1,0 +1,118 @@
+"""LBVH on the device: traversal result == brute force (GPU kernel and CPU oracle) bit-for-bit, structural invariants of
+the tree the kernels actually traverse, for LDS-resident and global-memory BVHs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_abi import check_lbvh
+
+pytestmark = pytest.mark.gpu
+
+
+def make_rays(spheres, n, seed):
+    """half the rays aimed at (jittered) spheres from points in the scene bounds, half random; unit directions"""
+    rng = np.random.default_rng(seed)
+    c = np.stack([spheres["cx"], spheres["cy"], spheres["cz"]], 1).astype(np.float64)
+    r = spheres["r"].astype(np.float64)
+    lo, hi = (c - r[:, None]).min(0), (c + r[:, None]).max(0)
+    lo = np.maximum(lo, -60); hi = np.minimum(hi, 60)  # keep most origins near the action (the ground sphere is huge)
+    o = rng.uniform(lo, hi, (n, 3))
+    pick = rng.integers(0, len(spheres), n)
+    target = c[pick] + rng.normal(size=(n, 3)) * r[pick, None] * 0.7
+    d = np.where((np.arange(n) % 2 == 0)[:, None], target - o, rng.normal(size=(n, 3)))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # rays starting ON a sphere surface (the secondary-ray case) for a quarter of them
+    k = np.arange(n) % 4 == 1
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    o[k] = c[pick[k]] + nrm[k] * r[pick[k], None] * (1 + 2 ** -14)
+    d32 = d.astype(np.float32)
+    d32 /= np.linalg.norm(d32.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+    return o.astype(np.float32), d32
+
+
+SCENES = [("small", 0), ("demo", 0), ("procedural", 3000), ("procedural", 40000), ("procedural", 200000)]
+
+
+@pytest.mark.parametrize("name,count", SCENES)
+@pytest.mark.parametrize("flags", [0, 1])  # 1 = PT_FLAG_NO_LDS_SCENE
+def test_bvh_equals_brute_force(dxrs, host, oracle, name, count, flags):
+    kind = {"small": dxrs.host.SCENE_SMALL, "demo": dxrs.host.SCENE_DEMO, "procedural": dxrs.host.SCENE_PROCEDURAL}[name]
+    spheres, materials, sd = host.scene(kind, seed=1, count=count)
+    r = dxrs.Renderer(flags=flags)
+    try:
+        info = r.set_scene(spheres, materials, sd)
+        assert info.leaf_count == len(spheres) and info.node_count == len(spheres) - 1
+        if flags:
+            assert info.lds_resident == 0
+        n = 200000 if len(spheres) < 50000 else 20000
+        o, d = make_rays(spheres, n, seed=len(spheres))
+        for tmin in (0.0, 0.5):
+            t_bvh, id_bvh = r.trace_rays(o, d, tmin=tmin, use_bvh=True)
+            t_bf, id_bf = r.trace_rays(o, d, tmin=tmin, use_bvh=False)
+            assert np.array_equal(id_bvh, id_bf)
+            assert np.array_equal(t_bvh.view(np.uint32), t_bf.view(np.uint32))
+            assert (id_bvh != 0xFFFFFFFF).mean() > 0.3
+        # CPU oracle on a subset: same closest hit, bit-exact t
+        sub = slice(0, 2000 if len(spheres) < 50000 else 300)
+        lib = oracle.lib
+        t_bvh, id_bvh = r.trace_rays(o[sub], d[sub], tmin=0.0, use_bvh=True)
+        for i in range(len(t_bvh)):
+            best, best_id = np.float32(np.inf), 0xFFFFFFFF
+            tt = C.c_float()
+            oi, di = np.ascontiguousarray(o[sub][i]), np.ascontiguousarray(d[sub][i])
+            cand = np.nonzero(candidates(spheres, oi, di))[0]
+            for sid in cand:
+                if lib.oracle_intersect_sphere(oi.ctypes.data_as(C.POINTER(C.c_float)), di.ctypes.data_as(C.POINTER(C.c_float)),
+                                               C.c_float(0.0), C.c_float(best), spheres[sid:sid + 1].ctypes.data, C.byref(tt)):
+                    best, best_id = np.float32(tt.value), sid
+            assert best_id == id_bvh[i] and (best_id == 0xFFFFFFFF or best == t_bvh[i])
+    finally:
+        r.close()
+
+
+def candidates(spheres, o, d):
+    """cheap float64 prefilter so the per-ray oracle loop only visits spheres the ray passes near (margin 1e-3 r)"""
+    c = np.stack([spheres["cx"], spheres["cy"], spheres["cz"]], 1).astype(np.float64) - o.astype(np.float64)
+    d = d.astype(np.float64); d = d / np.linalg.norm(d)  # a float32 "unit" vector is off by 6e-8: matters at b ~ 100
+    b = c @ d
+    dist2 = (c * c).sum(1) - b * b
+    rr = spheres["r"].astype(np.float64) * 1.01 + 1e-3
+    return dist2 <= rr * rr
+
+
+@pytest.mark.parametrize("name,count", [("small", 0), ("demo", 0), ("procedural", 50000)])
+def test_device_tree_structure(dxrs, host, name, count):
+    kind = {"small": dxrs.host.SCENE_SMALL, "demo": dxrs.host.SCENE_DEMO, "procedural": dxrs.host.SCENE_PROCEDURAL}[name]
+    spheres, materials, sd = host.scene(kind, seed=1, count=count)
+    r = dxrs.Renderer()
+    try:
+        info = r.set_scene(spheres, materials, sd)
+        nodes, order = r.download_accel()
+        check_lbvh(spheres, nodes, order, info.depth)
+        if name != "procedural":
+            assert info.lds_resident == 1  # small scenes: whole BVH staged in LDS
+        # the device tree is the same tree the host builder produces
+        hn, ho, hd = dxrs.load_hip().lbvh_build_host(spheres)
+        assert hd == info.depth and np.array_equal(ho, order)
+        assert np.array_equal(hn["child0"], nodes["child0"]) and np.array_equal(hn["child1"], nodes["child1"])
+    finally:
+        r.close()
+
+
+def test_single_sphere_scene(dxrs, host, oracle):
+    sph = np.zeros(1, dtype=dxrs.SPHERE_DTYPE); sph["r"] = 2.0; sph["cz"] = 1.0
+    m = dxrs.types.default_material(1); m["BaseColor"] = (0.8, 0.3, 0.2, 1); m["Transmission"] = 1; m["Roughness"] = 0.1
+    sd = host.scene(dxrs.host.SCENE_SMALL)[2]
+    gs = dxrs.types.graphics_settings(96, 64, bounces=6, spp=3)
+    cam = host.camera(96, 64, position=(0, 0, -6))
+    r = dxrs.Renderer()
+    try:
+        info = r.set_scene(sph, m, sd)
+        assert info.node_count == 0 and info.depth == 0
+        r.set_camera(cam); r.set_constants(gs)
+        img, st = r.render()
+        ref, ost = oracle.render(sph, m, sd, cam, gs, threads=4)
+        assert st.rays == ost.rays and np.array_equal(img.view(np.uint32)[..., :3], ref.view(np.uint32)[..., :3])
+    finally:
+        r.close()

@@ -1,0 +1,60 @@
+"""Partition invariance: a frame rendered as interleaved 32x32 tiles by 1, 2, 3 or 8 ranks and
+un-swizzled by pt_unpack_tiles is BIT-IDENTICAL to the single full-frame render.  The ranks are emulated one after
+another on the one GPU of the test box (the gather is a torch.cat standing in for the RCCL gather)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def tiled_render(dxrs, r, w, h, world, torch):
+    from dxrs_amd import tiles
+    ts = 32
+    max_tiles = tiles.tiles_count(w, h, 0, world)
+    gathered = torch.zeros((world, max_tiles * ts * ts, 4), dtype=torch.float32, device="cuda")
+    rays = 0
+    for rank in range(world):
+        r.set_partition(rank, world)
+        assert r.tiles_count(rank) == tiles.tiles_count(w, h, rank, world)
+        st = r.render_tiles(gathered[rank].data_ptr(), want_stats=True)
+        rays += st.rays
+    frame = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    r.set_partition(0, world)
+    r.unpack_tiles(gathered.data_ptr(), max_tiles, frame.data_ptr())
+    r.synchronize()
+    # device un-swizzle == the Python statement of the layout
+    ref = tiles.unpack_tiles(gathered.cpu().numpy().reshape(world, max_tiles, ts * ts, 4), w, h, world)
+    out = frame.cpu().numpy()
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    r.set_partition(0, 1)
+    return out, rays
+
+
+@pytest.mark.parametrize("w,h,spp,bounces,worlds", [(1920, 1080, 1, 8, (1, 2, 8)), (200, 150, 3, 4, (1, 2, 3, 8)), (3840, 2160, 2, 8, (8,))])
+def test_partition_invariance(dxrs, host, renderer, w, h, spp, bounces, worlds):
+    import torch
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    gs = dxrs.types.graphics_settings(w, h, frame_index=11, bounces=bounces, spp=spp)
+    cam = host.camera(w, h, jitter_index=11)
+    renderer.set_scene(spheres, materials, sd); renderer.set_camera(cam); renderer.set_constants(gs)
+    full, st = renderer.render()
+    for world in worlds:
+        img, rays = tiled_render(dxrs, renderer, w, h, world, torch)
+        assert rays == st.rays
+        assert np.array_equal(img.view(np.uint32)[..., :3], full.view(np.uint32)[..., :3]), f"world={world}"
+
+
+def test_full_frame_determinism_and_counts(dxrs, host, renderer):
+    """Full BASELINE C2 frame: run-to-run bit-identical although the queue order is decided by atomics; the ray count is
+    consistent with the structure of the estimator (primaries + at most spp*bounces per pixel)."""
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    w, h = 1920, 1080
+    gs = dxrs.types.graphics_settings(w, h, frame_index=2, bounces=8, spp=1)
+    renderer.set_scene(spheres, materials, sd); renderer.set_camera(host.camera(w, h, jitter_index=2)); renderer.set_constants(gs)
+    a, sa = renderer.render()
+    b, sb = renderer.render()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and sa.rays == sb.rays
+    assert sa.pixels == w * h and sa.paths == w * h and w * h < sa.rays <= w * h * 9
+    assert np.isfinite(a).all() and (a[..., :3] >= 0).all() and (a[..., 3] == 1).all()
+    # the sky rows at the top of the frame are pure environment: smooth and bluish
+    assert a[:8, :, 2].min() > a[:8, :, 0].max()
