@@ -170,17 +170,23 @@ def main():
             agg["pixels"] += int(st.pixels)
         r.set_profiling(False)
         if rank == 0:
-            slots = ((w + 7) // 8) * ((h + 7) // 8) * 64 * n_prof if world == 1 else r.tiles_count(0) * ts * ts * n_prof
+            # DESIGN.md byte model for the fused schedule: a compacting bounce pass reads 48 B per ray of its input queue
+            # (none for the primary pass, which generates its rays), writes 48 B per ray it emits and 16 B per pixel it
+            # finishes; the looping pass reads 48 B per queued ray and writes 16 B per pixel it finishes.
+            qs = r.queue_sizes() if args.spp == 1 else []
             secondary = agg["rays"] - agg["pixels"]
-            # DESIGN.md byte model.  traverse launches (incl. the primary launch): read o,d (32 B) + write hit (8 B) per
-            # secondary ray; the primary launch writes ray + hit (56 B) per slot.  shade launches: read ray + hit (56 B)
-            # per queue entry, write the next ray (48 B) per secondary ray, final store (16 B) per pixel.
-            bytes_trav = 40 * secondary + 56 * slots
-            bytes_shade = 56 * (slots + secondary) + 48 * secondary + 16 * agg["pixels"]
-            if agg["ms_trav"] >= agg["ms_shade"]:
-                name, b, ms, n = "traverse_kernel (+ primary_kernel)", bytes_trav, agg["ms_trav"], agg["n_trav"]
+            n_wf = agg["n_trav"] // n_prof  # compacting passes per frame (incl. the primary pass)
+            if qs and len(qs) > n_wf:
+                wf_in = sum(qs[1:n_wf]); wf_out = sum(qs[1:n_wf + 1]); loop_in = qs[n_wf]
+            else:  # no per-queue sizes (spp > 1): every secondary ray is written once and read once
+                wf_in = wf_out = secondary / n_prof; loop_in = 0
+            px = agg["pixels"] / n_prof
+            bytes_wf = (48 * wf_in + 48 * wf_out + 16 * px) * n_prof
+            bytes_loop = (48 * loop_in + 16 * loop_in) * n_prof
+            if agg["ms_trav"] >= agg["ms_tail"]:
+                name, b, ms, n = "bounce_kernel (compacting trace+shade passes)", bytes_wf, agg["ms_trav"], agg["n_trav"]
             else:
-                name, b, ms, n = "shade_kernel", bytes_shade, agg["ms_shade"], agg["n_shade"]
+                name, b, ms, n = "bounce_kernel<loop> (looping trace+shade pass)", bytes_loop, agg["ms_tail"], agg["n_tail"]
             achieved = (b / n) / (ms / n * 1e-3) / 1e9 if n and ms > 0 else 0.0
             result["roofline"] = {
                 "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -17,7 +17,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR
 API_SYMBOLS = [
     "pt_create", "pt_destroy", "pt_set_scene", "pt_build_accel", "pt_set_camera", "pt_set_constants", "pt_render",
     "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_trace_rays", "pt_accel_download",
-    "pt_accel_download_order", "pt_lbvh_build_host", "pt_set_profiling", "pt_get_totals", "pt_synchronize", "pt_last_error", "pt_version",
+    "pt_accel_download_order", "pt_lbvh_build_host", "pt_set_profiling", "pt_get_totals", "pt_get_queue_sizes", "pt_synchronize", "pt_last_error", "pt_version",
 ]
 
 
@@ -72,6 +72,8 @@ class HipLib:
         lib.pt_set_profiling.argtypes = [vp, C.c_int]
         lib.pt_get_totals.restype = C.c_int
         lib.pt_get_totals.argtypes = [vp, C.POINTER(PtStats), C.c_int]
+        lib.pt_get_queue_sizes.restype = C.c_int
+        lib.pt_get_queue_sizes.argtypes = [vp, vp, u32, C.POINTER(u32)]
         lib.pt_synchronize.restype = C.c_int
         lib.pt_synchronize.argtypes = [vp]
         lib.pt_last_error.restype = C.c_char_p
@@ -177,6 +179,13 @@ class Renderer:
         stats = PtStats()
         self._check(self._lib.pt_get_totals(self._ctx, C.byref(stats), 1 if reset else 0))
         return stats
+
+    def queue_sizes(self):
+        """Ray-queue sizes of the last spp == 1 frame: [slots, rays at bounce 1, rays at bounce 2, ...]."""
+        buf = np.zeros(256, dtype=np.uint32)
+        n = C.c_uint32(0)
+        self._check(self._lib.pt_get_queue_sizes(self._ctx, buf.ctypes.data, len(buf), C.byref(n)))
+        return [int(x) for x in buf[: n.value]]
 
     def synchronize(self):
         self._check(self._lib.pt_synchronize(self._ctx))

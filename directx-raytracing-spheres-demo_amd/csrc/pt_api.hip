@@ -70,8 +70,9 @@ struct PtContext {
     RayQueue q[2]{};
     Scratch scratch{};
     bool scratch_spp = false;
-    uint32_t* d_counts = nullptr;
+    uint32_t* d_counts = nullptr;  // two parities: [0, cap_counts) and [cap_counts, 2 cap_counts)
     size_t cap_counts = 0;
+    uint32_t parity = 0;           // parity of the frame being (or last) submitted
     uint32_t* h_counts = nullptr;  // pinned
     // queue sizes of a recent frame (pinned, written by an async copy, read without waiting): they only size the
     // launch grids -- every kernel is a grid-stride loop, so a stale or missing estimate costs time, never correctness
@@ -80,7 +81,7 @@ struct PtContext {
     float4* d_out = nullptr;
     size_t cap_out = 0;
     unsigned long long* d_totals = nullptr;  // [0] = secondary rays accumulated on the device
-    uint64_t tot_pixels = 0, tot_paths = 0, tot_slots = 0, tot_spp_paths = 0;  // host-known parts of the totals
+    uint64_t tot_pixels = 0, tot_paths = 0, tot_fixed_bytes = 0, tot_sec_coeff = 96;  // host-known parts of the totals
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profiling = false;
@@ -144,8 +145,8 @@ PtStatus ensure_buffers(PtContext* c, size_t n_slots, bool need_spp, size_t n_co
         PT_HIP(c, hipHostMalloc(&c->h_prev_counts, n_counts * sizeof(uint32_t)));
         std::memset(c->h_prev_counts, 0, n_counts * sizeof(uint32_t));
         c->prev_signature = 0;
-        PT_HIP(c, hipMalloc(&c->d_counts, n_counts * sizeof(uint32_t)));
-        PT_HIP(c, hipMemsetAsync(c->d_counts, 0, n_counts * sizeof(uint32_t), c->stream));
+        PT_HIP(c, hipMalloc(&c->d_counts, 2 * n_counts * sizeof(uint32_t)));
+        PT_HIP(c, hipMemsetAsync(c->d_counts, 0, 2 * n_counts * sizeof(uint32_t), c->stream));
         PT_HIP(c, hipHostMalloc(&c->h_counts, n_counts * sizeof(uint32_t)));
         c->cap_counts = n_counts;
     }
@@ -208,41 +209,60 @@ EventPair* next_events(PtContext* c, int kind)
     return p;
 }
 
-// DESIGN.md byte model (what the wavefront formulation must move through HBM):
-//   secondary ray = 48 (shade writes the ray) + 32 + 8 (traverse reads o,d, writes the hit) + 56 (shade reads ray + hit) = 144 B
-//   primary slot  = 56 (primary writes ray + hit) + 56 (shade reads them) = 112 B;  pixel = 16 B final store
-//   spp > 1: radiance read-modify-write (32) per sample + primary-hit cache (8 write + 8 read) = 48 B per path
-uint64_t algorithmic_bytes(uint64_t secondary, uint64_t slots, uint64_t pixels, uint64_t spp_paths)
+// DESIGN.md byte model (what the wavefront formulation must move through HBM).
+//   fused schedule: secondary ray = 48 (written by the pass that spawns it) + 48 (read by the pass that traces it) = 96 B;
+//                   primaries are generated, traced and shaded in registers: 0 B; pixel = 16 B final store
+//   split schedule: secondary ray = 48 + 32 + 8 (traverse reads o,d, writes the hit) + 56 (shade reads ray + hit) = 144 B;
+//                   primary slot = 56 (primary writes ray + hit) + 56 (shade reads them) = 112 B; pixel = 16 B
+//   spp > 1 (both): radiance read-modify-write (32) per sample + primary-hit cache (8 write + 8 read) = 48 B per path
+uint64_t bytes_per_secondary(bool split) { return split ? 144ull : 96ull; }
+uint64_t fixed_bytes(bool split, uint64_t slots, uint64_t pixels, uint64_t spp_paths)
 {
-    return 144ull * secondary + 112ull * slots + 16ull * pixels + 48ull * spp_paths;
+    return (split ? 112ull * slots : 0ull) + 16ull * pixels + 48ull * spp_paths;
 }
 
-FrameCounters make_counters(const PtContext* c)
+// d_totals: [0] running secondary-ray total, [1] last folded frame, [2] / [3] tail counters of parity 0 / 1
+FrameCounters make_counters(const PtContext* c, uint32_t parity)
 {
     FrameCounters fc{};
-    fc.counts = c->d_counts;
-    fc.n_counts = (uint32_t)c->cap_counts - 1u;  // the whole allocation is summed / zeroed every frame
-    fc.tail_rays = c->d_totals + 2;
+    fc.counts = c->d_counts + (size_t)parity * c->cap_counts;
+    fc.fold_counts = c->d_counts + (size_t)(parity ^ 1u) * c->cap_counts;
+    fc.n_counts = (uint32_t)c->cap_counts - 1u;  // the whole allocation is summed / zeroed when folded
+    fc.tail_rays = c->d_totals + 2 + parity;
+    fc.fold_tail = c->d_totals + 2 + (parity ^ 1u);
     fc.totals = c->d_totals;
     return fc;
 }
 
+// fold both parities into the totals (leaves all per-frame counters zero)
+hipError_t flush_all_counters(PtContext* c)
+{
+    if (!c->d_counts) return hipSuccess;
+    for (uint32_t p = 0; p < 2; p++) {
+        const FrameCounters fc = make_counters(c, p);
+        hipError_t e = launch_flush_counters(fc.counts, fc.n_counts, fc.tail_rays, fc.totals, c->stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 // The per-frame launch sequence.  out: device float4 buffer addressed by PixelRef::out_index.
 //
-//   primary -> shade(0) -> [traverse(k) -> shade(k)] for k = 1..S -> tail
-//
-// S wavefront bounces run as separate traverse / shade launches with stream compaction in between; after that the
-// queue is small and the fused tail kernel finishes every remaining path in one launch.  S = min(PT_TAIL_AFTER, ...)
-// for spp == 1; with spp > 1 (sample regeneration keeps the queue full) the host polls the queue size and switches to
-// the tail when it drops below PT_TAIL_THRESHOLD rays.
+// Fused schedule (default):  bounce<primary> -> bounce (x S) -> bounce<loop>
+//   every kernel traces its rays and runs one shade step; S compacting wavefront bounces, then the looping form
+//   finishes every remaining path in one launch.
+// Split schedule (PT_FLAG_SPLIT_KERNELS / PT_SPLIT=1):  primary -> shade(0) -> [traverse(k) -> shade(k)] x S -> tail
+//   separate traverse and shade kernels with a hit stream in between.
+// S = PT_TAIL_AFTER for spp == 1; with spp > 1 (sample regeneration keeps the queue full) the host polls the queue
+// size after every pass and switches to the looping kernel when it drops below PT_TAIL_THRESHOLD rays.
 PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, float4* out, PtStats* stats)
 {
     const uint32_t bounces = c->gs.Bounces, spp = c->gs.SamplesPerPixel;
-    const size_t max_iters = (size_t)spp * bounces + 1;  // shade passes if everything ran as wavefront; traverse passes = max_iters - 1
+    const size_t max_iters = (size_t)spp * bounces + 1;  // passes if everything ran as wavefront
     const size_t wf_cap = spp > 1 ? max_iters : std::min<size_t>(max_iters, 64);
     if (wf_cap + 2 > c->cap_counts && c->cap_counts) {
-        // growing the counter array: fold what the old one holds into the totals first
-        PT_HIP(c, launch_flush_counters(make_counters(c), c->stream));
+        // growing the counter arrays: fold what the old ones hold into the totals first
+        PT_HIP(c, flush_all_counters(c));
         PT_HIP(c, hipStreamSynchronize(c->stream));
     }
     PtStatus st = ensure_buffers(c, pm.n_slots, spp > 1, wf_cap + 2);
@@ -250,13 +270,16 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
 
     const SceneView sv = make_scene_view(c);
     const FrameParams fp = make_frame_params(c);
-    const FrameCounters fc = make_counters(c);
+    c->parity ^= 1u;
+    const FrameCounters fc = make_counters(c, c->parity);
+    uint32_t* counts = fc.counts;
     if (traverse_lds_bytes_for(sv.n_nodes, sv.n, sv.stack_depth, c->lds_scene) > kMaxLdsBytes)
         return fail(c, PT_ERR_UNSUPPORTED, "BVH depth needs more traversal-stack LDS than a workgroup can have");
+    const bool split = (c->flags & PT_FLAG_SPLIT_KERNELS) || env_u32("PT_SPLIT", 0);
 
     // Launch grids: a kernel's queue size lives on the device; the host sizes the grid from the queue sizes an
     // earlier frame of the same configuration had (1.25x margin), falling back to the n_slots upper bound.
-    const uint64_t signature = ((uint64_t)pm.n_slots << 32) ^ ((uint64_t)bounces << 20) ^ ((uint64_t)spp << 4) ^ pm.mode ^ ((uint64_t)c->n << 40);
+    const uint64_t signature = ((uint64_t)pm.n_slots << 32) ^ ((uint64_t)bounces << 20) ^ ((uint64_t)spp << 4) ^ pm.mode ^ ((uint64_t)c->n << 40) ^ (split ? 8u : 0u);
     const bool have_prev = spp == 1 && c->prev_signature == signature && c->h_prev_counts[0] == pm.n_slots && !std::getenv("PT_NO_ADAPTIVE_GRID");
     auto estimate = [&](size_t k) -> uint32_t {
         if (!have_prev || k >= c->cap_counts) return pm.n_slots;
@@ -268,9 +291,10 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     const uint32_t tail_cap = c->num_cus * env_u32("PT_TAIL_BLOCKS_PER_CU", 8);
     auto grid_for = [](uint32_t items, uint32_t threads, uint32_t cap) { return std::max(1u, std::min((items + threads - 1) / threads, cap)); };
     const uint32_t trav_threads = traverse_threads(c->lds_scene);
-    const uint32_t trav_grid = grid_for(pm.n_slots, trav_threads, trav_cap);
-    const size_t tail_after = env_u32("PT_TAIL_AFTER", 2);           // wavefront bounces before the tail (spp == 1)
-    const uint32_t tail_threshold = env_u32("PT_TAIL_THRESHOLD", 262144);  // queue size below which spp > 1 switches to the tail
+    const uint32_t fused_threads = c->lds_scene ? env_u32("PT_FUSED_THREADS", 256) : 256u;
+    const uint32_t loop_threads = 256u;
+    const size_t tail_after = env_u32("PT_TAIL_AFTER", 1);                 // wavefront bounces before the looping kernel (spp == 1)
+    const uint32_t tail_threshold = env_u32("PT_TAIL_THRESHOLD", 262144);  // queue size below which spp > 1 switches to it
 
     const bool timed = stats != nullptr;
     c->ev_used = 0;
@@ -283,51 +307,92 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         if (ev) (void)hipEventRecord(ev->b, c->stream);
         return e;
     };
-
-    PT_HIP(c, bracket(0, [&] { return launch_primary(sv, pm, fp, c->q[0], c->scratch, out, fc, trav_grid, c->stream); }));
-
-    // shade pass k consumes queue k (counts[k]) and appends to queue k+1; queue k+1 is then traversed, or handed to the tail
-    for (size_t k = 0;; k++) {
-        const RayQueue& qin = c->q[k & 1];
-        const RayQueue& qout = c->q[(k + 1) & 1];
-        PT_HIP(c, bracket(2, [&] { return launch_shade(sv, pm, fp, qin, qout, c->scratch, out, c->d_counts + k, c->d_counts + k + 1, grid_for(estimate(k), kShadeThreads, shade_cap), c->stream); }));
-        if (k + 1 == max_iters) break;  // no path can have another ray
-        bool go_tail;
+    // decide, after pass k has filled queue k+1, whether the looping kernel takes over (and whether anything is left)
+    auto poll = [&](size_t k, bool& empty, bool& go_loop) -> PtStatus {
+        empty = false;
         if (spp > 1) {
-            PT_HIP(c, hipMemcpyAsync(c->h_counts, c->d_counts + k + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            PT_HIP(c, hipMemcpyAsync(c->h_counts, counts + k + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             PT_HIP(c, hipStreamSynchronize(c->stream));
-            if (c->h_counts[0] == 0) break;
-            go_tail = c->h_counts[0] < tail_threshold || k + 2 >= wf_cap;
+            empty = c->h_counts[0] == 0;
+            go_loop = c->h_counts[0] < tail_threshold || k + 2 >= wf_cap;
         } else {
-            go_tail = k >= tail_after || k + 2 >= wf_cap;
+            go_loop = k >= tail_after || k + 2 >= wf_cap;
         }
-        if (go_tail) {
-            PT_HIP(c, bracket(3, [&] { return launch_tail(sv, pm, fp, qout, c->scratch, out, c->d_counts + k + 1, fc.tail_rays, grid_for(estimate(k + 1), kTailThreads, tail_cap), c->stream); }));
-            break;
+        return PT_OK;
+    };
+
+    if (!split) {
+        // pass 0 generates + traces the primaries and shades them into queue 1; pass k >= 1 consumes queue k
+        for (size_t k = 0;; k++) {
+            const RayQueue& qin = c->q[k & 1];
+            const RayQueue& qout = c->q[(k + 1) & 1];
+            const bool primary = k == 0;
+            bool go_loop = false, empty = false;
+            if (k > 0) {
+                // queue k exists: is it worth another compacting pass?
+                if ((st = poll(k - 1, empty, go_loop)) != PT_OK) return st;
+                if (empty) break;
+            }
+            const bool last_possible = k + 1 >= max_iters;  // no path can have another ray after this pass
+            const bool loop = (k > 0 && go_loop);
+            const uint32_t threads = loop ? loop_threads : fused_threads;
+            const uint32_t items = primary ? pm.n_slots : estimate(k);
+            const uint32_t cap = loop ? tail_cap : trav_cap;
+            if (loop && std::getenv("PT_LOOP_USE_TAIL")) {
+                PT_HIP(c, launch_tail(sv, pm, fp, qin, c->scratch, out, counts + k, fc.tail_rays, grid_for(items, kTailThreads, tail_cap), c->stream));
+                break;
+            }
+            PT_HIP(c, bracket(loop ? 3 : (primary ? 0 : 1), [&] {
+                return launch_bounce(sv, pm, fp, qin, qout, c->scratch, out, counts + k, counts + k + 1, fc, primary, loop, threads,
+                                     grid_for(items, threads, cap), c->stream);
+            }));
+            if (loop || last_possible) break;
         }
-        PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, c->d_counts + k + 1, grid_for(estimate(k + 1), trav_threads, trav_cap), c->stream); }));
+    } else {
+        const uint32_t trav_grid = grid_for(pm.n_slots, trav_threads, trav_cap);
+        PT_HIP(c, bracket(0, [&] { return launch_primary(sv, pm, fp, c->q[0], c->scratch, out, fc, trav_grid, c->stream); }));
+        // shade pass k consumes queue k (counts[k]) and appends to queue k+1; queue k+1 is then traversed, or handed to the tail
+        for (size_t k = 0;; k++) {
+            const RayQueue& qin = c->q[k & 1];
+            const RayQueue& qout = c->q[(k + 1) & 1];
+            PT_HIP(c, bracket(2, [&] { return launch_shade(sv, pm, fp, qin, qout, c->scratch, out, counts + k, counts + k + 1, grid_for(estimate(k), kShadeThreads, shade_cap), c->stream); }));
+            if (k + 1 == max_iters) break;  // no path can have another ray
+            bool go_loop = false, empty = false;
+            if ((st = poll(k, empty, go_loop)) != PT_OK) return st;
+            if (empty) break;
+            if (go_loop) {
+                PT_HIP(c, bracket(3, [&] { return launch_tail(sv, pm, fp, qout, c->scratch, out, counts + k + 1, fc.tail_rays, grid_for(estimate(k + 1), kTailThreads, tail_cap), c->stream); }));
+                break;
+            }
+            PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, counts + k + 1, grid_for(estimate(k + 1), trav_threads, trav_cap), c->stream); }));
+        }
     }
     if (spp == 1) {
         // remember this frame's queue sizes for the next frame's grid sizing (no wait: see h_prev_counts)
-        PT_HIP(c, hipMemcpyAsync(c->h_prev_counts, c->d_counts, c->cap_counts * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        PT_HIP(c, hipMemcpyAsync(c->h_prev_counts, counts, c->cap_counts * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         c->prev_signature = signature;
     }
     c->tot_pixels += valid_pixels;
     c->tot_paths += valid_pixels * spp;
-    c->tot_slots += pm.n_slots;
-    if (spp > 1) c->tot_spp_paths += valid_pixels * spp;
+    c->tot_fixed_bytes += fixed_bytes(split, pm.n_slots, valid_pixels, spp > 1 ? valid_pixels * spp : 0);
+    c->tot_sec_coeff = bytes_per_secondary(split);
     if (timed) {
         PT_HIP(c, hipEventRecord(c->ev1, c->stream));
-        // fold this frame's counters now so that its ray count can be read back
         if (std::getenv("PT_DEBUG_COUNTS")) {
             std::vector<uint32_t> hc(c->cap_counts);
-            PT_HIP(c, hipMemcpyAsync(hc.data(), c->d_counts, c->cap_counts * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            PT_HIP(c, hipMemcpyAsync(hc.data(), counts, c->cap_counts * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             PT_HIP(c, hipStreamSynchronize(c->stream));
             std::fprintf(stderr, "[pt] queue sizes:");
             for (size_t k = 0; k < c->cap_counts && k < 20; k++) std::fprintf(stderr, " %u", hc[k]);
             std::fprintf(stderr, "\n");
         }
-        PT_HIP(c, launch_flush_counters(fc, c->stream));
+        // fold the previous frame first (normally done by the next frame's first kernel), then this one, so that
+        // totals[1] is this frame's secondary-ray count
+        {
+            const FrameCounters other = make_counters(c, c->parity ^ 1u);
+            PT_HIP(c, launch_flush_counters(other.counts, other.n_counts, other.tail_rays, other.totals, c->stream));
+            PT_HIP(c, launch_flush_counters(fc.counts, fc.n_counts, fc.tail_rays, fc.totals, c->stream));
+        }
         unsigned long long secondary = 0;
         PT_HIP(c, hipMemcpyAsync(&secondary, c->d_totals + 1, sizeof secondary, hipMemcpyDeviceToHost, c->stream));
         PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -338,7 +403,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         stats->rays = valid_pixels + secondary;
         stats->pixels = valid_pixels;
         stats->paths = valid_pixels * spp;
-        stats->bytes_algorithmic = algorithmic_bytes(secondary, pm.n_slots, valid_pixels, spp > 1 ? valid_pixels * spp : 0);
+        stats->bytes_algorithmic = bytes_per_secondary(split) * secondary + fixed_bytes(split, pm.n_slots, valid_pixels, spp > 1 ? valid_pixels * spp : 0);
         if (c->profiling) {
             for (size_t i = 0; i < c->ev_used; i++) {
                 float t = 0;
@@ -346,7 +411,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
                 switch (c->ev_pool[i].kind) {
                     case 2: stats->ms_shade += t; stats->shade_launches++; break;
                     case 3: stats->ms_tail += t; stats->tail_launches++; break;
-                    default: stats->ms_traverse += t; stats->traverse_launches++; break;  // the primary launch counts as a traverse launch
+                    default: stats->ms_traverse += t; stats->traverse_launches++; break;  // primary / fused bounce / traverse
                 }
             }
         }
@@ -685,18 +750,35 @@ PtStatus pt_get_totals(PtContext* c, PtStats* totals, int reset)
     if (!totals) return fail(c, PT_ERR_INVALID_ARG, "pt_get_totals: null output");
     PT_HIP(c, hipSetDevice(c->device));
     unsigned long long secondary = 0;
-    if (c->d_counts) PT_HIP(c, launch_flush_counters(make_counters(c), c->stream));  // fold the last frame in
+    PT_HIP(c, flush_all_counters(c));  // fold the frames still sitting in the per-frame counters
     PT_HIP(c, hipMemcpyAsync(&secondary, c->d_totals, sizeof secondary, hipMemcpyDeviceToHost, c->stream));
     PT_HIP(c, hipStreamSynchronize(c->stream));
     std::memset(totals, 0, sizeof *totals);
     totals->rays = c->tot_pixels + secondary;
     totals->paths = c->tot_paths;
     totals->pixels = c->tot_pixels;
-    totals->bytes_algorithmic = algorithmic_bytes(secondary, c->tot_slots, c->tot_pixels, c->tot_spp_paths);
+    totals->bytes_algorithmic = c->tot_sec_coeff * secondary + c->tot_fixed_bytes;
     if (reset) {
         PT_HIP(c, hipMemsetAsync(c->d_totals, 0, 2 * sizeof(unsigned long long), c->stream));
-        c->tot_pixels = c->tot_paths = c->tot_slots = c->tot_spp_paths = 0;
+        c->tot_pixels = c->tot_paths = c->tot_fixed_bytes = 0;
     }
+    return PT_OK;
+}
+
+PtStatus pt_get_queue_sizes(PtContext* c, uint32_t* sizes, uint32_t capacity, uint32_t* n)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!sizes || !n) return fail(c, PT_ERR_INVALID_ARG, "pt_get_queue_sizes: null pointer");
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    *n = 0;
+    if (!c->h_prev_counts || !c->prev_signature) return PT_OK;
+    uint32_t k = 0;
+    for (; k < c->cap_counts && k < capacity; k++) {
+        sizes[k] = c->h_prev_counts[k];
+        if (k > 0 && sizes[k] == 0) break;
+    }
+    *n = k;
     return PT_OK;
 }
 

@@ -96,12 +96,18 @@ struct FrameParams {
     float throughput_threshold;
 };
 
-// Per-frame device counters.  counts[k] = size of ray queue k (queue 0 = all slots); tail_rays = rays traced by the
-// fused tail kernel; totals[0] = running sum of secondary rays over finished frames, totals[1] = last finished frame.
+// Per-frame device counters, double buffered by frame parity so that the first kernel of a frame can append to this
+// frame's counters while its block 0 folds the PREVIOUS frame's into the running totals and zeroes them for the next.
+//   counts[k]  = size of ray queue k of this frame (counts[0] = all slots), appended with one atomicAdd per workgroup
+//   tail_rays  = rays spawned inside looping kernels of this frame (they never enter a queue)
+//   fold_*     = the other parity's counters (a finished frame)
+//   totals[0]  = running sum of secondary rays over folded frames, totals[1] = secondary rays of the last folded frame
 struct FrameCounters {
     uint32_t* counts;
-    uint32_t n_counts;  // counts[0..n_counts] are valid
+    uint32_t* fold_counts;
+    uint32_t n_counts;  // counts[0..n_counts] are valid in both arrays
     unsigned long long* tail_rays;
+    unsigned long long* fold_tail;
     unsigned long long* totals;
 };
 

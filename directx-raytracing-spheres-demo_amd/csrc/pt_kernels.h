@@ -11,6 +11,7 @@ constexpr uint32_t kTraverseThreads = 512;  // launch bound; 8 waves share one L
 inline uint32_t traverse_threads(bool lds_scene) { return lds_scene ? kTraverseThreads : 256u; }
 constexpr uint32_t kShadeThreads = 256;
 constexpr uint32_t kTailThreads = 256;
+constexpr uint32_t kFusedThreads = 512;  // launch bound of the fused trace+shade kernel (launched with 512 or 256 threads)
 
 // dynamic LDS a traverse-type launch needs (scene copy if lds_scene, plus the per-lane stacks)
 uint32_t traverse_lds_bytes_for(uint32_t n_nodes, uint32_t n, uint32_t depth, bool lds_scene, uint32_t threads = 0);
@@ -24,7 +25,10 @@ hipError_t launch_trace(const SceneView& sv, const float* o, const float* d, uin
                         uint32_t* out_id, hipStream_t stream);
 hipError_t launch_tail(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const Scratch& scratch, float4* out,
                        const uint32_t* count_ptr, unsigned long long* tail_rays, uint32_t grid, hipStream_t stream);
-hipError_t launch_flush_counters(const FrameCounters& fc, hipStream_t stream);
+hipError_t launch_flush_counters(uint32_t* counts, uint32_t n_counts, unsigned long long* tail, unsigned long long* totals, hipStream_t stream);
+hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const RayQueue& qout,
+                         const Scratch& scratch, float4* out, const uint32_t* count_in, uint32_t* count_out, const FrameCounters& fc,
+                         bool primary, bool loop, uint32_t threads, uint32_t grid, hipStream_t stream);
 hipError_t launch_unpack_tiles(const float4* gathered, float4* frame, uint32_t w, uint32_t h, uint32_t ts, uint32_t tiles_x, uint32_t world,
                                uint32_t max_tiles, hipStream_t stream);
 

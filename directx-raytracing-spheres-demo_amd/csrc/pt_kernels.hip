@@ -21,27 +21,35 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// Called by every thread of ONE block.  totals[0] += secondary rays of the frame that just finished
-// (tail counter + queue sizes 1..n); then tail = 0, counts[0] = n_slots, counts[1..n] = 0.
-__device__ __forceinline__ void frame_counters_begin(const FrameCounters& fc, uint32_t n_slots)
+// Called by every thread of ONE block: fold a finished frame's counters (queue sizes 1..n + its tail counter) into
+// the running totals and leave them zeroed.
+__device__ __forceinline__ void fold_counters(uint32_t* __restrict__ counts, uint32_t n_counts, unsigned long long* __restrict__ tail,
+                                              unsigned long long* __restrict__ totals)
 {
     __shared__ unsigned long long s_sum[16];
     unsigned long long s = 0;
-    for (uint32_t k = 1 + threadIdx.x; k <= fc.n_counts; k += blockDim.x) s += fc.counts[k];
+    for (uint32_t k = 1 + threadIdx.x; k <= n_counts; k += blockDim.x) s += counts[k];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63u) == 0) s_sum[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long t = *fc.tail_rays;
+        unsigned long long t = *tail;
         for (uint32_t w = 0; w < (blockDim.x + 63u) / 64u; w++) t += s_sum[w];
-        fc.totals[0] += t;
-        fc.totals[1] = t;  // secondary rays of the last finished frame
-        *fc.tail_rays = 0ull;
-        fc.counts[0] = n_slots;
+        totals[0] += t;
+        totals[1] = t;
+        *tail = 0ull;
     }
     __syncthreads();
-    for (uint32_t k = 1 + threadIdx.x; k <= fc.n_counts; k += blockDim.x) fc.counts[k] = 0u;
+    for (uint32_t k = threadIdx.x; k <= n_counts; k += blockDim.x) counts[k] = 0u;
+}
+
+// First kernel of a frame, block 0: fold the previous frame (other parity), publish this frame's queue-0 size.
+// This frame's counters were zeroed when the frame before the previous one was folded (or at allocation).
+__device__ __forceinline__ void frame_counters_begin(const FrameCounters& fc, uint32_t n_slots)
+{
+    fold_counters(fc.fold_counts, fc.n_counts, fc.fold_tail, fc.totals);
+    if (threadIdx.x == 0) fc.counts[0] = n_slots;
 }
 
 // Stage the BVH (nodes, Morton-ordered spheres, ids) into LDS.  Layout: [nodes | spheres | ids].
@@ -449,6 +457,103 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(SceneView sv, PixelM
     if (lane_id() == 0 && total) atomicAdd(tail_rays, total);
 }
 
+// ------------------------------------------------------------------------------------------------ fused bounce
+// trace + shade in one kernel (DESIGN.md "Kernels"): a lane obtains a ray (kPrimary: generated from its pixel; else read
+// from the input queue), traces it, and runs one shade_step.  kLoop = false: survivors are compacted into the output
+// queue (wave64 ballot + prefix, one atomic per workgroup) -- one wavefront bounce per launch, 96 B of queue traffic
+// per ray and no hit stream.  kLoop = true: the lane keeps alternating trace and shade_step until its pixel is done
+// (the persistent "tail" form for small queues).
+template <bool kLds, typename StackT, bool kPrimary, bool kLoop>
+__global__ __launch_bounds__(kFusedThreads) void bounce_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue qin, RayQueue qout,
+                                                               Scratch scratch, float4* __restrict__ out,
+                                                               const uint32_t* __restrict__ count_in_ptr, uint32_t* __restrict__ count_out_ptr,
+                                                               FrameCounters fc)
+{
+    extern __shared__ float4 smem[];
+    __shared__ uint32_t s_wave_count[kFusedThreads / 64];
+    __shared__ uint32_t s_block_base;
+    if (kPrimary && blockIdx.x == 0) frame_counters_begin(fc, pm.n_slots);
+    const uint32_t count = kPrimary ? pm.n_slots : *count_in_ptr;
+    if (blockIdx.x * blockDim.x >= count) return;
+    const float4* nodes = sv.nodes;
+    const float4* sph = sv.sph_sorted;
+    const uint32_t* ids = sv.sorted_id;
+    StackT* stack;
+    if (kLds) {
+        stage_scene(sv, smem);
+        nodes = smem;
+        sph = smem + sv.n_nodes * 4u;
+        ids = reinterpret_cast<const uint32_t*>(smem + sv.n_nodes * 4u + sv.n);
+        stack = reinterpret_cast<StackT*>(reinterpret_cast<char*>(smem) + scene_lds_bytes(sv.n_nodes, sv.n));
+    } else {
+        stack = reinterpret_cast<StackT*>(smem);
+    }
+    stack += threadIdx.x;
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t my_rays = 0;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        bool emit = false;
+        PathState ps;
+        if (i < count) {
+            bool live = true;
+            float tmin = 0.0f, tmax = kInf;
+            if (kPrimary) {
+                const PixelRef pr = slot_to_pixel(pm, i);
+                live = pr.valid;
+                ps.slot = i; ps.bounce = 0; ps.sample = 0; ps.dirty = false; ps.rng = 0;
+                ps.T = make_f3(1.f, 1.f, 1.f);
+                ps.o = make_f3(0.f, 0.f, 0.f); ps.d = make_f3(0.f, 0.f, 1.f);
+                if (live) {
+                    primary_ray(fp.cam, pr.px, pr.py, pm.img_w, pm.img_h, ps.o, ps.d, tmin, tmax);
+                    ps.rng = rng_init(pr.px, pr.py, fp.frame_index);
+                } else if (pm.mode == 1) {
+                    out[pr.out_index] = make_float4(0.f, 0.f, 0.f, 0.f);  // padding pixel of an edge tile
+                }
+            } else {
+                ps = load_path(qin, i);
+            }
+            if (live) {
+                bool primary_trace = kPrimary;
+                for (;;) {
+                    float t;
+                    uint32_t id;
+                    closest_hit<StackT>(nodes, sph, ids, sv.n, ps.o, ps.d, tmin, tmax, stack, blockDim.x, t, id);
+                    if (kPrimary && primary_trace && fp.spp > 1) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
+                    primary_trace = false;
+                    emit = shade_step(sv, pm, fp, scratch, out, ps, t, id);
+                    if (!kLoop || !emit) break;
+                    my_rays++;  // a ray spawned inside the looping kernel (queued rays are counted by counts[])
+                    tmin = 0.0f; tmax = kInf;
+                }
+            }
+        }
+        if (!kLoop) {
+            const unsigned long long mask = __ballot(emit);
+            const uint32_t wave_n = __popcll(mask);
+            const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wave_count[wave] = wave_n;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t total = 0;
+                const uint32_t n_waves = blockDim.x >> 6;
+                for (uint32_t w = 0; w < n_waves; w++) { const uint32_t c = s_wave_count[w]; s_wave_count[w] = total; total += c; }
+                s_block_base = total ? atomicAdd(count_out_ptr, total) : 0u;
+            }
+            __syncthreads();
+            if (emit) store_path(qout, s_block_base + s_wave_count[wave] + prefix, ps);
+            __syncthreads();
+        }
+    }
+    if (kLoop) {
+        unsigned long long total = my_rays;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
+        if (lane == 0 && total) atomicAdd(fc.tail_rays, total);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ test hooks
 template <bool kLds, typename StackT>
 __global__ __launch_bounds__(kTraverseThreads) void trace_kernel(SceneView sv, const float* __restrict__ o, const float* __restrict__ d,
@@ -510,10 +615,10 @@ __global__ void unpack_tiles_kernel(const float4* __restrict__ gathered, float4*
 }
 
 // totals[0] += sum of counts[1..n_iters] (secondary rays of this frame); one thread
-// Fold the last frame's counters into the running total (pt_get_totals / stats); leaves the counters zeroed.
-__global__ void flush_counters_kernel(FrameCounters fc)
+// Fold one parity's counters into the running total (pt_get_totals / stats); leaves them zeroed.
+__global__ void flush_counters_kernel(uint32_t* counts, uint32_t n_counts, unsigned long long* tail, unsigned long long* totals)
 {
-    if (blockIdx.x == 0) frame_counters_begin(fc, 0u);
+    if (blockIdx.x == 0) fold_counters(counts, n_counts, tail, totals);
 }
 
 // ------------------------------------------------------------------------------------------------ launch wrappers
@@ -578,6 +683,30 @@ hipError_t launch_tail(const SceneView& sv, const PixelMap& pm, const FrameParam
     return hipGetLastError();
 }
 
+hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const RayQueue& qout,
+                         const Scratch& scratch, float4* out, const uint32_t* count_in, uint32_t* count_out, const FrameCounters& fc,
+                         bool primary, bool loop, uint32_t threads, uint32_t grid, hipStream_t stream)
+{
+    const bool small = sv.n_nodes < 32767u;
+    const uint32_t elem = small ? 2u : 4u;
+    const uint32_t lds = (sv.lds_scene ? scene_lds_bytes(sv.n_nodes, sv.n) : 0u) + threads * sv.stack_depth * elem;
+#define PT_BOUNCE3(L, T, P, LP)                                                                                            \
+    do {                                                                                                                    \
+        if (lds > 65536u) (void)hipFuncSetAttribute((const void*)bounce_kernel<L, T, P, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((bounce_kernel<L, T, P, LP>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out, fc); \
+    } while (0)
+#define PT_BOUNCE2(L, T)                                                                                                    \
+    do {                                                                                                                    \
+        if (primary) { if (loop) PT_BOUNCE3(L, T, true, true); else PT_BOUNCE3(L, T, true, false); }                        \
+        else { if (loop) PT_BOUNCE3(L, T, false, true); else PT_BOUNCE3(L, T, false, false); }                              \
+    } while (0)
+    if (sv.lds_scene) { if (small) PT_BOUNCE2(true, uint16_t); else PT_BOUNCE2(true, uint32_t); }
+    else { if (small) PT_BOUNCE2(false, uint16_t); else PT_BOUNCE2(false, uint32_t); }
+#undef PT_BOUNCE2
+#undef PT_BOUNCE3
+    return hipGetLastError();
+}
+
 hipError_t launch_shade(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const RayQueue& qout,
                         const Scratch& scratch, float4* out, const uint32_t* count_in, uint32_t* count_out, uint32_t grid, hipStream_t stream)
 {
@@ -599,9 +728,9 @@ hipError_t launch_trace(const SceneView& sv, const float* o, const float* d, uin
     return hipGetLastError();
 }
 
-hipError_t launch_flush_counters(const FrameCounters& fc, hipStream_t stream)
+hipError_t launch_flush_counters(uint32_t* counts, uint32_t n_counts, unsigned long long* tail, unsigned long long* totals, hipStream_t stream)
 {
-    hipLaunchKernelGGL(flush_counters_kernel, dim3(1), dim3(256), 0, stream, fc);
+    hipLaunchKernelGGL(flush_counters_kernel, dim3(1), dim3(256), 0, stream, counts, n_counts, tail, totals);
     return hipGetLastError();
 }
 

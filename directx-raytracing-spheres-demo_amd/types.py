@@ -92,6 +92,7 @@ assert SPHERE_DTYPE.itemsize == 16 and MATERIAL_DTYPE.itemsize == 64 and BVH_NOD
 PT_FLAG_NO_LDS_SCENE = 1
 PT_FLAG_NO_GRAPH = 2
 PT_FLAG_HOST_LBVH = 4
+PT_FLAG_SPLIT_KERNELS = 8
 
 
 def default_material(n=1):

@@ -55,7 +55,8 @@ typedef struct PtConfig {
 enum {
     PT_FLAG_NO_LDS_SCENE = 1u,   /* never stage the BVH into LDS (debug / A-B) */
     PT_FLAG_NO_GRAPH = 2u,       /* do not capture the per-frame launch sequence into a hipGraph */
-    PT_FLAG_HOST_LBVH = 4u       /* build the LBVH on the host instead of on the GPU (debug / A-B) */
+    PT_FLAG_HOST_LBVH = 4u,      /* build the LBVH on the host instead of on the GPU (debug / A-B) */
+    PT_FLAG_SPLIT_KERNELS = 8u   /* separate traverse / shade kernels with a hit stream instead of the fused bounce kernel */
 };
 
 typedef struct PtAccelInfo {
@@ -140,6 +141,9 @@ PtStatus pt_set_profiling(PtContext *ctx, int enabled);
 /* Running totals over every render call since the last reset, accumulated on the device without host
  * synchronisation (rays, paths, pixels, bytes_algorithmic; the timing fields are zero).  Synchronises the stream. */
 PtStatus pt_get_totals(PtContext *ctx, PtStats *totals, int reset);
+/* Queue sizes of the last spp == 1 frame: sizes[k] = rays in queue k (sizes[0] = path slots).  Returns the number of
+ * valid entries through *n (0 if none).  Synchronises the stream. */
+PtStatus pt_get_queue_sizes(PtContext *ctx, uint32_t *sizes, uint32_t capacity, uint32_t *n);
 PtStatus pt_synchronize(PtContext *ctx);
 
 const char *pt_last_error(PtContext *ctx);
