@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--scene", choices=["demo", "small", "procedural"], default="demo")
     ap.add_argument("--spheres", type=int, default=1 << 20, help="sphere count of the procedural scene")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
+                    help="2: consecutive frames alternate between two streams / output buffers so one frame's tail overlaps the next frame's start")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="the CPU baseline renders every n-th row of each frame")
@@ -65,18 +67,24 @@ def main():
     spheres, materials, sd = host.scene(kind, seed=1 if args.scene == "procedural" else 0, count=args.spheres)
     w, h = args.width, args.height
 
-    stream = torch.cuda.current_stream(dev).cuda_stream  # kernels run on torch's stream so RCCL ops order after them
-    r = dxrs_amd.Renderer(device=local_rank, stream=stream)
+    # a real (non-default) torch stream: the renderer's kernels and the RCCL gather are ordered through it
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    r = dxrs_amd.Renderer(device=local_rank, stream=stream, flags=0 if args.frames_in_flight < 2 else dxrs_amd.types.PT_FLAG_TWO_FRAMES_IN_FLIGHT)
     accel = r.set_scene(spheres, materials, sd)
     r.set_partition(rank, world)
     gs = graphics_settings(w, h, frame_index=0, bounces=args.bounces, spp=args.spp)
     r.set_constants(gs)
     ts = 32
+    # double-buffered outputs: frame k writes buffer k % 2 (the swap chain of the reference, two frames in flight)
     if world == 1:
-        frame = torch.empty((h * w, 4), dtype=torch.float32, device=dev)
+        frames = [torch.empty((h * w, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        frame = frames[0]
     else:
         max_tiles = r.tiles_count(0)
-        packed = torch.zeros((max_tiles * ts * ts, 4), dtype=torch.float32, device=dev)
+        packeds = [torch.zeros((max_tiles * ts * ts, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        packed = packeds[0]
         if rank == 0:
             gathered = torch.empty((world, max_tiles * ts * ts, 4), dtype=torch.float32, device=dev)
             gather_list = list(gathered.unbind(0))
@@ -89,10 +97,10 @@ def main():
         r.set_camera(cams[k % 8])
         r.set_constants(gs)
         if world == 1:
-            r.render_device(frame.data_ptr())
+            r.render_device(frames[k % 2].data_ptr())
         else:
-            r.render_tiles(packed.data_ptr())
-            dist.gather(packed, gather_list if rank == 0 else None, dst=0)
+            r.render_tiles(packeds[k % 2].data_ptr())
+            dist.gather(packeds[k % 2], gather_list if rank == 0 else None, dst=0)
             if rank == 0:
                 r.unpack_tiles(gathered.data_ptr(), max_tiles, frame.data_ptr())
 

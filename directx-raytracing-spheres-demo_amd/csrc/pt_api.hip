@@ -32,6 +32,26 @@ struct EventPair {
 
 }  // namespace
 
+// Per-frame-in-flight state (see PtContext::lanes).
+struct Lane {
+    hipStream_t stream = nullptr;  // == PtContext::stream when there is a single lane
+    hipEvent_t ev_done = nullptr;
+    size_t cap_slots = 0;
+    RayQueue q[2]{};
+    Scratch scratch{};
+    bool scratch_spp = false;
+    uint32_t* d_counts = nullptr;  // two parities: [0, cap_counts) and [cap_counts, 2 cap_counts)
+    size_t cap_counts = 0;
+    uint32_t parity = 0;           // parity of the frame being (or last) submitted on this lane
+    uint32_t* h_counts = nullptr;  // pinned
+    // queue sizes of a recent frame (pinned, written by an async copy, read without waiting): they only size the
+    // launch grids -- every kernel is a grid-stride loop, so a stale or missing estimate costs time, never correctness
+    uint32_t* h_prev_counts = nullptr;
+    uint64_t prev_signature = 0;
+    unsigned long long* d_totals = nullptr;  // [0] running secondary-ray total, [1] last folded frame, [2],[3] tail counters
+};
+constexpr uint32_t kMaxLanes = 2;
+
 struct PtContext {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -65,22 +85,16 @@ struct PtContext {
     bool cam_set = false, gs_set = false;
     uint32_t rank = 0, world = 1;
 
-    // work buffers
-    size_t cap_slots = 0;
-    RayQueue q[2]{};
-    Scratch scratch{};
-    bool scratch_spp = false;
-    uint32_t* d_counts = nullptr;  // two parities: [0, cap_counts) and [cap_counts, 2 cap_counts)
-    size_t cap_counts = 0;
-    uint32_t parity = 0;           // parity of the frame being (or last) submitted
-    uint32_t* h_counts = nullptr;  // pinned
-    // queue sizes of a recent frame (pinned, written by an async copy, read without waiting): they only size the
-    // launch grids -- every kernel is a grid-stride loop, so a stale or missing estimate costs time, never correctness
-    uint32_t* h_prev_counts = nullptr;
-    uint64_t prev_signature = 0;
+    // work buffers: one set per frame in flight.  Frame f runs on lane f % n_lanes, on that lane's own stream, so the
+    // latency-bound looping pass of one frame overlaps the throughput-bound first passes of the next.
+    Lane lanes[kMaxLanes];
+    uint32_t n_lanes = 1;
+    uint32_t next_lane = 0;
+    uint32_t last_lane = 0;
+    hipEvent_t ev_in[2] = { nullptr, nullptr };  // markers on `stream` at the start of the last two render calls
+    uint64_t calls = 0;
     float4* d_out = nullptr;
     size_t cap_out = 0;
-    unsigned long long* d_totals = nullptr;  // [0] = secondary rays accumulated on the device
     uint64_t tot_pixels = 0, tot_paths = 0, tot_fixed_bytes = 0, tot_sec_coeff = 96;  // host-known parts of the totals
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -112,45 +126,54 @@ void free_dev(T*& p)
     if (p) { (void)hipFree(p); p = nullptr; }
 }
 
-void free_queues(PtContext* c)
+void free_lane_buffers(Lane& L)
 {
-    for (auto& q : c->q) { free_dev(q.q0); free_dev(q.q1); free_dev(q.q2); free_dev(q.hit); }
-    free_dev(c->scratch.sample_rad); free_dev(c->scratch.radiance); free_dev(c->scratch.primary_hit);
-    c->cap_slots = 0;
-    c->scratch_spp = false;
+    for (auto& q : L.q) { free_dev(q.q0); free_dev(q.q1); free_dev(q.q2); free_dev(q.hit); }
+    free_dev(L.scratch.sample_rad); free_dev(L.scratch.radiance); free_dev(L.scratch.primary_hit);
+    L.cap_slots = 0;
+    L.scratch_spp = false;
 }
 
-PtStatus ensure_buffers(PtContext* c, size_t n_slots, bool need_spp, size_t n_counts)
+PtStatus ensure_buffers(PtContext* c, Lane& L, size_t n_slots, bool need_spp, bool need_hits, size_t n_counts)
 {
-    if (n_slots > c->cap_slots) {
-        free_queues(c);
-        for (auto& q : c->q) {
+    if (n_slots > L.cap_slots || (need_hits && !L.q[0].hit)) {
+        PT_HIP(c, hipStreamSynchronize(L.stream));
+        free_lane_buffers(L);
+        for (auto& q : L.q) {
             PT_HIP(c, hipMalloc(&q.q0, n_slots * sizeof(float4)));
             PT_HIP(c, hipMalloc(&q.q1, n_slots * sizeof(float4)));
             PT_HIP(c, hipMalloc(&q.q2, n_slots * sizeof(float4)));
-            PT_HIP(c, hipMalloc(&q.hit, n_slots * sizeof(uint2)));
+            if (need_hits) PT_HIP(c, hipMalloc(&q.hit, n_slots * sizeof(uint2)));  // split schedule only
         }
-        PT_HIP(c, hipMalloc(&c->scratch.sample_rad, n_slots * sizeof(float4)));
-        c->cap_slots = n_slots;
+        PT_HIP(c, hipMalloc(&L.scratch.sample_rad, n_slots * sizeof(float4)));
+        L.cap_slots = n_slots;
     }
-    if (need_spp && !c->scratch_spp) {
-        PT_HIP(c, hipMalloc(&c->scratch.radiance, c->cap_slots * sizeof(float4)));
-        PT_HIP(c, hipMalloc(&c->scratch.primary_hit, c->cap_slots * sizeof(uint2)));
-        c->scratch_spp = true;
+    if (need_spp && !L.scratch_spp) {
+        PT_HIP(c, hipMalloc(&L.scratch.radiance, L.cap_slots * sizeof(float4)));
+        PT_HIP(c, hipMalloc(&L.scratch.primary_hit, L.cap_slots * sizeof(uint2)));
+        L.scratch_spp = true;
     }
-    if (n_counts > c->cap_counts) {
-        free_dev(c->d_counts);
-        if (c->h_counts) { (void)hipHostFree(c->h_counts); c->h_counts = nullptr; }
-        if (c->h_prev_counts) { (void)hipHostFree(c->h_prev_counts); c->h_prev_counts = nullptr; }
-        PT_HIP(c, hipHostMalloc(&c->h_prev_counts, n_counts * sizeof(uint32_t)));
-        std::memset(c->h_prev_counts, 0, n_counts * sizeof(uint32_t));
-        c->prev_signature = 0;
-        PT_HIP(c, hipMalloc(&c->d_counts, 2 * n_counts * sizeof(uint32_t)));
-        PT_HIP(c, hipMemsetAsync(c->d_counts, 0, 2 * n_counts * sizeof(uint32_t), c->stream));
-        PT_HIP(c, hipHostMalloc(&c->h_counts, n_counts * sizeof(uint32_t)));
-        c->cap_counts = n_counts;
+    if (n_counts > L.cap_counts) {
+        free_dev(L.d_counts);
+        if (L.h_counts) { (void)hipHostFree(L.h_counts); L.h_counts = nullptr; }
+        if (L.h_prev_counts) { (void)hipHostFree(L.h_prev_counts); L.h_prev_counts = nullptr; }
+        PT_HIP(c, hipHostMalloc(&L.h_prev_counts, n_counts * sizeof(uint32_t)));
+        std::memset(L.h_prev_counts, 0, n_counts * sizeof(uint32_t));
+        L.prev_signature = 0;
+        PT_HIP(c, hipMalloc(&L.d_counts, 2 * n_counts * sizeof(uint32_t)));
+        PT_HIP(c, hipMemsetAsync(L.d_counts, 0, 2 * n_counts * sizeof(uint32_t), L.stream));
+        PT_HIP(c, hipHostMalloc(&L.h_counts, n_counts * sizeof(uint32_t)));
+        L.cap_counts = n_counts;
     }
     return PT_OK;
+}
+
+// wait for every frame in flight
+hipError_t sync_all(PtContext* c)
+{
+    for (uint32_t i = 0; i < c->n_lanes; i++)
+        if (c->lanes[i].stream) { hipError_t e = hipStreamSynchronize(c->lanes[i].stream); if (e != hipSuccess) return e; }
+    return c->stream ? hipStreamSynchronize(c->stream) : hipSuccess;
 }
 
 PtStatus validate_frame(PtContext* c)
@@ -221,26 +244,25 @@ uint64_t fixed_bytes(bool split, uint64_t slots, uint64_t pixels, uint64_t spp_p
     return (split ? 112ull * slots : 0ull) + 16ull * pixels + 48ull * spp_paths;
 }
 
-// d_totals: [0] running secondary-ray total, [1] last folded frame, [2] / [3] tail counters of parity 0 / 1
-FrameCounters make_counters(const PtContext* c, uint32_t parity)
+FrameCounters make_counters(const Lane& L, uint32_t parity)
 {
     FrameCounters fc{};
-    fc.counts = c->d_counts + (size_t)parity * c->cap_counts;
-    fc.fold_counts = c->d_counts + (size_t)(parity ^ 1u) * c->cap_counts;
-    fc.n_counts = (uint32_t)c->cap_counts - 1u;  // the whole allocation is summed / zeroed when folded
-    fc.tail_rays = c->d_totals + 2 + parity;
-    fc.fold_tail = c->d_totals + 2 + (parity ^ 1u);
-    fc.totals = c->d_totals;
+    fc.counts = L.d_counts + (size_t)parity * L.cap_counts;
+    fc.fold_counts = L.d_counts + (size_t)(parity ^ 1u) * L.cap_counts;
+    fc.n_counts = (uint32_t)L.cap_counts - 1u;  // the whole allocation is summed / zeroed when folded
+    fc.tail_rays = L.d_totals + 2 + parity;
+    fc.fold_tail = L.d_totals + 2 + (parity ^ 1u);
+    fc.totals = L.d_totals;
     return fc;
 }
 
-// fold both parities into the totals (leaves all per-frame counters zero)
-hipError_t flush_all_counters(PtContext* c)
+// fold both parities of a lane into its totals (leaves all per-frame counters zero)
+hipError_t flush_all_counters(Lane& L)
 {
-    if (!c->d_counts) return hipSuccess;
+    if (!L.d_counts) return hipSuccess;
     for (uint32_t p = 0; p < 2; p++) {
-        const FrameCounters fc = make_counters(c, p);
-        hipError_t e = launch_flush_counters(fc.counts, fc.n_counts, fc.tail_rays, fc.totals, c->stream);
+        const FrameCounters fc = make_counters(L, p);
+        hipError_t e = launch_flush_counters(fc.counts, fc.n_counts, fc.tail_rays, fc.totals, L.stream);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -260,30 +282,43 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     const uint32_t bounces = c->gs.Bounces, spp = c->gs.SamplesPerPixel;
     const size_t max_iters = (size_t)spp * bounces + 1;  // passes if everything ran as wavefront
     const size_t wf_cap = spp > 1 ? max_iters : std::min<size_t>(max_iters, 64);
-    if (wf_cap + 2 > c->cap_counts && c->cap_counts) {
+    const bool split = (c->flags & PT_FLAG_SPLIT_KERNELS) || env_u32("PT_SPLIT", 0);
+    // frames in flight: this frame runs on the next lane (its own stream and work buffers)
+    Lane& L = c->lanes[c->next_lane];
+    c->last_lane = c->next_lane;
+    c->next_lane = (c->next_lane + 1) % c->n_lanes;
+    if (wf_cap + 2 > L.cap_counts && L.cap_counts) {
         // growing the counter arrays: fold what the old ones hold into the totals first
-        PT_HIP(c, flush_all_counters(c));
-        PT_HIP(c, hipStreamSynchronize(c->stream));
+        PT_HIP(c, flush_all_counters(L));
+        PT_HIP(c, hipStreamSynchronize(L.stream));
     }
-    PtStatus st = ensure_buffers(c, pm.n_slots, spp > 1, wf_cap + 2);
+    PtStatus st = ensure_buffers(c, L, pm.n_slots, spp > 1, split, wf_cap + 2);
     if (st != PT_OK) return st;
+    if (L.stream != c->stream) {
+        // Two frames in flight.  The caller alternates between two output buffers, so this frame may start as soon as
+        // the consumer of ITS buffer (queued on the caller's stream before the previous render call) has run: wait for
+        // the marker recorded at the start of the previous call -- not for the previous frame itself, whose completion
+        // wait was queued on the caller's stream after that marker.
+        PT_HIP(c, hipEventRecord(c->ev_in[c->calls & 1], c->stream));
+        PT_HIP(c, hipStreamWaitEvent(L.stream, c->ev_in[c->calls ? (c->calls - 1) & 1 : 0], 0));
+        c->calls++;
+    }
 
     const SceneView sv = make_scene_view(c);
     const FrameParams fp = make_frame_params(c);
-    c->parity ^= 1u;
-    const FrameCounters fc = make_counters(c, c->parity);
+    L.parity ^= 1u;
+    const FrameCounters fc = make_counters(L, L.parity);
     uint32_t* counts = fc.counts;
     if (traverse_lds_bytes_for(sv.n_nodes, sv.n, sv.stack_depth, c->lds_scene) > kMaxLdsBytes)
         return fail(c, PT_ERR_UNSUPPORTED, "BVH depth needs more traversal-stack LDS than a workgroup can have");
-    const bool split = (c->flags & PT_FLAG_SPLIT_KERNELS) || env_u32("PT_SPLIT", 0);
 
     // Launch grids: a kernel's queue size lives on the device; the host sizes the grid from the queue sizes an
     // earlier frame of the same configuration had (1.25x margin), falling back to the n_slots upper bound.
     const uint64_t signature = ((uint64_t)pm.n_slots << 32) ^ ((uint64_t)bounces << 20) ^ ((uint64_t)spp << 4) ^ pm.mode ^ ((uint64_t)c->n << 40) ^ (split ? 8u : 0u);
-    const bool have_prev = spp == 1 && c->prev_signature == signature && c->h_prev_counts[0] == pm.n_slots && !std::getenv("PT_NO_ADAPTIVE_GRID");
+    const bool have_prev = spp == 1 && L.prev_signature == signature && L.h_prev_counts[0] == pm.n_slots && !std::getenv("PT_NO_ADAPTIVE_GRID");
     auto estimate = [&](size_t k) -> uint32_t {
-        if (!have_prev || k >= c->cap_counts) return pm.n_slots;
-        const uint64_t e = (uint64_t)c->h_prev_counts[k] + c->h_prev_counts[k] / 4 + 64;
+        if (!have_prev || k >= L.cap_counts) return pm.n_slots;
+        const uint64_t e = (uint64_t)L.h_prev_counts[k] + L.h_prev_counts[k] / 4 + 64;
         return (uint32_t)std::min<uint64_t>(e, pm.n_slots);
     };
     const uint32_t trav_cap = c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", 8);
@@ -298,23 +333,23 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
 
     const bool timed = stats != nullptr;
     c->ev_used = 0;
-    if (timed) PT_HIP(c, hipEventRecord(c->ev0, c->stream));
+    if (timed) PT_HIP(c, hipEventRecord(c->ev0, L.stream));
 
     auto bracket = [&](int kind, auto&& launch) -> hipError_t {
         EventPair* ev = c->profiling ? next_events(c, kind) : nullptr;
-        if (ev) (void)hipEventRecord(ev->a, c->stream);
+        if (ev) (void)hipEventRecord(ev->a, L.stream);
         hipError_t e = launch();
-        if (ev) (void)hipEventRecord(ev->b, c->stream);
+        if (ev) (void)hipEventRecord(ev->b, L.stream);
         return e;
     };
     // decide, after pass k has filled queue k+1, whether the looping kernel takes over (and whether anything is left)
     auto poll = [&](size_t k, bool& empty, bool& go_loop) -> PtStatus {
         empty = false;
         if (spp > 1) {
-            PT_HIP(c, hipMemcpyAsync(c->h_counts, counts + k + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            PT_HIP(c, hipStreamSynchronize(c->stream));
-            empty = c->h_counts[0] == 0;
-            go_loop = c->h_counts[0] < tail_threshold || k + 2 >= wf_cap;
+            PT_HIP(c, hipMemcpyAsync(L.h_counts, counts + k + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, L.stream));
+            PT_HIP(c, hipStreamSynchronize(L.stream));
+            empty = L.h_counts[0] == 0;
+            go_loop = L.h_counts[0] < tail_threshold || k + 2 >= wf_cap;
         } else {
             go_loop = k >= tail_after || k + 2 >= wf_cap;
         }
@@ -324,8 +359,8 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     if (!split) {
         // pass 0 generates + traces the primaries and shades them into queue 1; pass k >= 1 consumes queue k
         for (size_t k = 0;; k++) {
-            const RayQueue& qin = c->q[k & 1];
-            const RayQueue& qout = c->q[(k + 1) & 1];
+            const RayQueue& qin = L.q[k & 1];
+            const RayQueue& qout = L.q[(k + 1) & 1];
             const bool primary = k == 0;
             bool go_loop = false, empty = false;
             if (k > 0) {
@@ -339,63 +374,68 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
             const uint32_t items = primary ? pm.n_slots : estimate(k);
             const uint32_t cap = loop ? tail_cap : trav_cap;
             if (loop && std::getenv("PT_LOOP_USE_TAIL")) {
-                PT_HIP(c, launch_tail(sv, pm, fp, qin, c->scratch, out, counts + k, fc.tail_rays, grid_for(items, kTailThreads, tail_cap), c->stream));
+                PT_HIP(c, launch_tail(sv, pm, fp, qin, L.scratch, out, counts + k, fc.tail_rays, grid_for(items, kTailThreads, tail_cap), L.stream));
                 break;
             }
             PT_HIP(c, bracket(loop ? 3 : (primary ? 0 : 1), [&] {
-                return launch_bounce(sv, pm, fp, qin, qout, c->scratch, out, counts + k, counts + k + 1, fc, primary, loop, threads,
-                                     grid_for(items, threads, cap), c->stream);
+                return launch_bounce(sv, pm, fp, qin, qout, L.scratch, out, counts + k, counts + k + 1, fc, primary, loop, threads,
+                                     grid_for(items, threads, cap), L.stream);
             }));
             if (loop || last_possible) break;
         }
     } else {
         const uint32_t trav_grid = grid_for(pm.n_slots, trav_threads, trav_cap);
-        PT_HIP(c, bracket(0, [&] { return launch_primary(sv, pm, fp, c->q[0], c->scratch, out, fc, trav_grid, c->stream); }));
+        PT_HIP(c, bracket(0, [&] { return launch_primary(sv, pm, fp, L.q[0], L.scratch, out, fc, trav_grid, L.stream); }));
         // shade pass k consumes queue k (counts[k]) and appends to queue k+1; queue k+1 is then traversed, or handed to the tail
         for (size_t k = 0;; k++) {
-            const RayQueue& qin = c->q[k & 1];
-            const RayQueue& qout = c->q[(k + 1) & 1];
-            PT_HIP(c, bracket(2, [&] { return launch_shade(sv, pm, fp, qin, qout, c->scratch, out, counts + k, counts + k + 1, grid_for(estimate(k), kShadeThreads, shade_cap), c->stream); }));
+            const RayQueue& qin = L.q[k & 1];
+            const RayQueue& qout = L.q[(k + 1) & 1];
+            PT_HIP(c, bracket(2, [&] { return launch_shade(sv, pm, fp, qin, qout, L.scratch, out, counts + k, counts + k + 1, grid_for(estimate(k), kShadeThreads, shade_cap), L.stream); }));
             if (k + 1 == max_iters) break;  // no path can have another ray
             bool go_loop = false, empty = false;
             if ((st = poll(k, empty, go_loop)) != PT_OK) return st;
             if (empty) break;
             if (go_loop) {
-                PT_HIP(c, bracket(3, [&] { return launch_tail(sv, pm, fp, qout, c->scratch, out, counts + k + 1, fc.tail_rays, grid_for(estimate(k + 1), kTailThreads, tail_cap), c->stream); }));
+                PT_HIP(c, bracket(3, [&] { return launch_tail(sv, pm, fp, qout, L.scratch, out, counts + k + 1, fc.tail_rays, grid_for(estimate(k + 1), kTailThreads, tail_cap), L.stream); }));
                 break;
             }
-            PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, counts + k + 1, grid_for(estimate(k + 1), trav_threads, trav_cap), c->stream); }));
+            PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, counts + k + 1, grid_for(estimate(k + 1), trav_threads, trav_cap), L.stream); }));
         }
     }
     if (spp == 1) {
         // remember this frame's queue sizes for the next frame's grid sizing (no wait: see h_prev_counts)
-        PT_HIP(c, hipMemcpyAsync(c->h_prev_counts, counts, c->cap_counts * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        c->prev_signature = signature;
+        PT_HIP(c, hipMemcpyAsync(L.h_prev_counts, counts, L.cap_counts * sizeof(uint32_t), hipMemcpyDeviceToHost, L.stream));
+        L.prev_signature = signature;
+    }
+    if (L.stream != c->stream) {
+        // whatever the caller queues next on its stream (a gather, a copy, the next use of `out`) sees the finished frame
+        PT_HIP(c, hipEventRecord(L.ev_done, L.stream));
+        PT_HIP(c, hipStreamWaitEvent(c->stream, L.ev_done, 0));
     }
     c->tot_pixels += valid_pixels;
     c->tot_paths += valid_pixels * spp;
     c->tot_fixed_bytes += fixed_bytes(split, pm.n_slots, valid_pixels, spp > 1 ? valid_pixels * spp : 0);
     c->tot_sec_coeff = bytes_per_secondary(split);
     if (timed) {
-        PT_HIP(c, hipEventRecord(c->ev1, c->stream));
+        PT_HIP(c, hipEventRecord(c->ev1, L.stream));
         if (std::getenv("PT_DEBUG_COUNTS")) {
-            std::vector<uint32_t> hc(c->cap_counts);
-            PT_HIP(c, hipMemcpyAsync(hc.data(), counts, c->cap_counts * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            PT_HIP(c, hipStreamSynchronize(c->stream));
+            std::vector<uint32_t> hc(L.cap_counts);
+            PT_HIP(c, hipMemcpyAsync(hc.data(), counts, L.cap_counts * sizeof(uint32_t), hipMemcpyDeviceToHost, L.stream));
+            PT_HIP(c, hipStreamSynchronize(L.stream));
             std::fprintf(stderr, "[pt] queue sizes:");
-            for (size_t k = 0; k < c->cap_counts && k < 20; k++) std::fprintf(stderr, " %u", hc[k]);
+            for (size_t k = 0; k < L.cap_counts && k < 20; k++) std::fprintf(stderr, " %u", hc[k]);
             std::fprintf(stderr, "\n");
         }
         // fold the previous frame first (normally done by the next frame's first kernel), then this one, so that
         // totals[1] is this frame's secondary-ray count
         {
-            const FrameCounters other = make_counters(c, c->parity ^ 1u);
-            PT_HIP(c, launch_flush_counters(other.counts, other.n_counts, other.tail_rays, other.totals, c->stream));
-            PT_HIP(c, launch_flush_counters(fc.counts, fc.n_counts, fc.tail_rays, fc.totals, c->stream));
+            const FrameCounters other = make_counters(L, L.parity ^ 1u);
+            PT_HIP(c, launch_flush_counters(other.counts, other.n_counts, other.tail_rays, other.totals, L.stream));
+            PT_HIP(c, launch_flush_counters(fc.counts, fc.n_counts, fc.tail_rays, fc.totals, L.stream));
         }
         unsigned long long secondary = 0;
-        PT_HIP(c, hipMemcpyAsync(&secondary, c->d_totals + 1, sizeof secondary, hipMemcpyDeviceToHost, c->stream));
-        PT_HIP(c, hipStreamSynchronize(c->stream));
+        PT_HIP(c, hipMemcpyAsync(&secondary, L.d_totals + 1, sizeof secondary, hipMemcpyDeviceToHost, L.stream));
+        PT_HIP(c, hipStreamSynchronize(L.stream));
         std::memset(stats, 0, sizeof *stats);
         float ms = 0;
         PT_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -453,15 +493,24 @@ PtStatus pt_create(const PtConfig* config, PtContext** out_ctx)
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return PT_ERR_HIP; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = (uint32_t)prop.multiProcessorCount;
-    if (config->stream) {
-        c->stream = reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(config->stream));
+    if (config->stream || (config->flags & PT_FLAG_DEFAULT_STREAM)) {
+        c->stream = reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(config->stream));  // 0 = legacy default stream
     } else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PT_ERR_HIP; }
         c->own_stream = true;
     }
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
-    if (hipMalloc(&c->d_totals, 4 * sizeof(unsigned long long)) != hipSuccess
-        || hipMemsetAsync(c->d_totals, 0, 4 * sizeof(unsigned long long), c->stream) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess
+        || hipEventCreateWithFlags(&c->ev_in[0], hipEventDisableTiming) != hipSuccess
+        || hipEventCreateWithFlags(&c->ev_in[1], hipEventDisableTiming) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
+    c->n_lanes = (config->flags & PT_FLAG_TWO_FRAMES_IN_FLIGHT) ? kMaxLanes : 1u;
+    for (uint32_t i = 0; i < c->n_lanes; i++) {
+        Lane& L = c->lanes[i];
+        if (c->n_lanes == 1) L.stream = c->stream;
+        else if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
+        if (hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) != hipSuccess
+            || hipMalloc(&L.d_totals, 4 * sizeof(unsigned long long)) != hipSuccess
+            || hipMemsetAsync(L.d_totals, 0, 4 * sizeof(unsigned long long), L.stream) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
+    }
     *out_ctx = c;
     return PT_OK;
 }
@@ -470,12 +519,18 @@ void pt_destroy(PtContext* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    free_queues(c);
+    (void)sync_all(c);
+    for (auto& L : c->lanes) {
+        free_lane_buffers(L);
+        free_dev(L.d_counts); free_dev(L.d_totals);
+        if (L.h_counts) (void)hipHostFree(L.h_counts);
+        if (L.h_prev_counts) (void)hipHostFree(L.h_prev_counts);
+        if (L.ev_done) (void)hipEventDestroy(L.ev_done);
+        if (L.stream && L.stream != c->stream) (void)hipStreamDestroy(L.stream);
+    }
     free_dev(c->d_sph); free_dev(c->d_mats); free_dev(c->d_nodes); free_dev(c->d_sph_sorted); free_dev(c->d_sorted_id);
-    free_dev(c->d_counts); free_dev(c->d_out); free_dev(c->d_totals);
-    if (c->h_counts) (void)hipHostFree(c->h_counts);
-    if (c->h_prev_counts) (void)hipHostFree(c->h_prev_counts);
+    free_dev(c->d_out);
+    for (auto& e : c->ev_in) if (e) (void)hipEventDestroy(e);
     if (c->gpu_builder) lbvh_gpu_destroy(c->gpu_builder);
     for (auto& p : c->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -497,8 +552,8 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
         if (!(spheres[i].r > 0.0f) || !std::isfinite(spheres[i].r) || !std::isfinite(spheres[i].cx) || !std::isfinite(spheres[i].cy) || !std::isfinite(spheres[i].cz))
             return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: sphere " + std::to_string(i) + " has a non-finite centre or non-positive radius");
     PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, sync_all(c));  // frames in flight still read the old scene
     if (n != c->n) {
-        PT_HIP(c, hipStreamSynchronize(c->stream));
         free_dev(c->d_sph); free_dev(c->d_mats);
         PT_HIP(c, hipMalloc(&c->d_sph, (size_t)n * sizeof(float4)));
         PT_HIP(c, hipMalloc(&c->d_mats, (size_t)n * sizeof(PtMaterial)));
@@ -520,7 +575,7 @@ PtStatus pt_build_accel(PtContext* c, PtAccelInfo* info)
     if (!c->scene_set) return fail(c, PT_ERR_STATE, "pt_build_accel: no scene");
     PT_HIP(c, hipSetDevice(c->device));
     const uint32_t n = c->n;
-    PT_HIP(c, hipStreamSynchronize(c->stream));
+    PT_HIP(c, sync_all(c));
     if (c->n_nodes != (n > 1 ? n - 1 : 0) || !c->d_sph_sorted) {
         free_dev(c->d_nodes); free_dev(c->d_sph_sorted); free_dev(c->d_sorted_id);
         PT_HIP(c, hipMalloc(&c->d_nodes, (size_t)std::max(1u, n - 1) * sizeof(PtBvhNode)));
@@ -634,7 +689,7 @@ PtStatus pt_render(PtContext* c, const PtRect* rect, void* out, int out_is_devic
     const size_t out_px = (size_t)r.w * r.h;
     if (!out_is_device) {
         if (out_px > c->cap_out) {
-            PT_HIP(c, hipStreamSynchronize(c->stream));
+            PT_HIP(c, sync_all(c));
             free_dev(c->d_out);
             PT_HIP(c, hipMalloc(&c->d_out, out_px * sizeof(float4)));
             c->cap_out = out_px;
@@ -750,18 +805,21 @@ PtStatus pt_get_totals(PtContext* c, PtStats* totals, int reset)
     if (!totals) return fail(c, PT_ERR_INVALID_ARG, "pt_get_totals: null output");
     PT_HIP(c, hipSetDevice(c->device));
     unsigned long long secondary = 0;
-    PT_HIP(c, flush_all_counters(c));  // fold the frames still sitting in the per-frame counters
-    PT_HIP(c, hipMemcpyAsync(&secondary, c->d_totals, sizeof secondary, hipMemcpyDeviceToHost, c->stream));
-    PT_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < c->n_lanes; i++) {
+        Lane& L = c->lanes[i];
+        unsigned long long s = 0;
+        PT_HIP(c, flush_all_counters(L));  // fold the frames still sitting in the per-frame counters
+        PT_HIP(c, hipMemcpyAsync(&s, L.d_totals, sizeof s, hipMemcpyDeviceToHost, L.stream));
+        PT_HIP(c, hipStreamSynchronize(L.stream));
+        secondary += s;
+        if (reset) PT_HIP(c, hipMemsetAsync(L.d_totals, 0, 2 * sizeof(unsigned long long), L.stream));
+    }
     std::memset(totals, 0, sizeof *totals);
     totals->rays = c->tot_pixels + secondary;
     totals->paths = c->tot_paths;
     totals->pixels = c->tot_pixels;
     totals->bytes_algorithmic = c->tot_sec_coeff * secondary + c->tot_fixed_bytes;
-    if (reset) {
-        PT_HIP(c, hipMemsetAsync(c->d_totals, 0, 2 * sizeof(unsigned long long), c->stream));
-        c->tot_pixels = c->tot_paths = c->tot_fixed_bytes = 0;
-    }
+    if (reset) c->tot_pixels = c->tot_paths = c->tot_fixed_bytes = 0;
     return PT_OK;
 }
 
@@ -770,12 +828,13 @@ PtStatus pt_get_queue_sizes(PtContext* c, uint32_t* sizes, uint32_t capacity, ui
     if (!c) return PT_ERR_INVALID_ARG;
     if (!sizes || !n) return fail(c, PT_ERR_INVALID_ARG, "pt_get_queue_sizes: null pointer");
     PT_HIP(c, hipSetDevice(c->device));
-    PT_HIP(c, hipStreamSynchronize(c->stream));
+    PT_HIP(c, sync_all(c));
     *n = 0;
-    if (!c->h_prev_counts || !c->prev_signature) return PT_OK;
+    const Lane& L = c->lanes[c->last_lane];
+    if (!L.h_prev_counts || !L.prev_signature) return PT_OK;
     uint32_t k = 0;
-    for (; k < c->cap_counts && k < capacity; k++) {
-        sizes[k] = c->h_prev_counts[k];
+    for (; k < L.cap_counts && k < capacity; k++) {
+        sizes[k] = L.h_prev_counts[k];
         if (k > 0 && sizes[k] == 0) break;
     }
     *n = k;
@@ -786,7 +845,7 @@ PtStatus pt_synchronize(PtContext* c)
 {
     if (!c) return PT_ERR_INVALID_ARG;
     PT_HIP(c, hipSetDevice(c->device));
-    PT_HIP(c, hipStreamSynchronize(c->stream));
+    PT_HIP(c, sync_all(c));
     return PT_OK;
 }
 

@@ -93,6 +93,8 @@ PT_FLAG_NO_LDS_SCENE = 1
 PT_FLAG_NO_GRAPH = 2
 PT_FLAG_HOST_LBVH = 4
 PT_FLAG_SPLIT_KERNELS = 8
+PT_FLAG_TWO_FRAMES_IN_FLIGHT = 16
+PT_FLAG_DEFAULT_STREAM = 32
 
 
 def default_material(n=1):

@@ -47,7 +47,8 @@ typedef enum PtStatus {
 typedef struct PtConfig {
     int32_t device;         /* HIP device ordinal */
     uint32_t tile_size;     /* multi-GPU tile edge in pixels; 0 -> 32 */
-    uint64_t stream;        /* hipStream_t to run on (e.g. torch's current stream); 0 -> context-owned stream */
+    uint64_t stream;        /* hipStream_t to run on (e.g. a torch.cuda.Stream's handle); 0 -> context-owned stream, or the
+                               legacy default (null) stream with PT_FLAG_DEFAULT_STREAM */
     uint32_t flags;         /* PT_FLAG_* */
     uint32_t _reserved;
 } PtConfig;
@@ -56,7 +57,12 @@ enum {
     PT_FLAG_NO_LDS_SCENE = 1u,   /* never stage the BVH into LDS (debug / A-B) */
     PT_FLAG_NO_GRAPH = 2u,       /* do not capture the per-frame launch sequence into a hipGraph */
     PT_FLAG_HOST_LBVH = 4u,      /* build the LBVH on the host instead of on the GPU (debug / A-B) */
-    PT_FLAG_SPLIT_KERNELS = 8u   /* separate traverse / shade kernels with a hit stream instead of the fused bounce kernel */
+    PT_FLAG_SPLIT_KERNELS = 8u,  /* separate traverse / shade kernels with a hit stream instead of the fused bounce kernel */
+    PT_FLAG_DEFAULT_STREAM = 32u, /* with stream == 0: run on the legacy default stream instead of a context-owned one */
+    PT_FLAG_TWO_FRAMES_IN_FLIGHT = 16u /* consecutive render calls alternate between two internal streams (and two sets of
+                                          work buffers) so that the latency-bound tail of one frame overlaps the start of
+                                          the next.  The caller must alternate between two output buffers; whatever it
+                                          queues on `stream` after a render call is ordered after that frame. */
 };
 
 typedef struct PtAccelInfo {
