@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--spheres", type=int, default=1 << 20, help="sphere count of the procedural scene")
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
                     help="2: consecutive frames alternate between two streams / output buffers so one frame's tail overlaps the next frame's start")
+    ap.add_argument("--force-tiles", action="store_true", help="run the tile / gather / un-swizzle path even with one rank (rehearsal of the N > 1 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="the CPU baseline renders every n-th row of each frame")
@@ -58,9 +59,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    tiled = world > 1 or args.force_tiles
+    if tiled:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     host = dxrs_amd.load_host()
     kind = {"demo": dxrs_amd.host.SCENE_DEMO, "small": dxrs_amd.host.SCENE_SMALL, "procedural": dxrs_amd.host.SCENE_PROCEDURAL}[args.scene]
@@ -78,7 +81,7 @@ def main():
     r.set_constants(gs)
     ts = 32
     # double-buffered outputs: frame k writes buffer k % 2 (the swap chain of the reference, two frames in flight)
-    if world == 1:
+    if not tiled:
         frames = [torch.empty((h * w, 4), dtype=torch.float32, device=dev) for _ in range(2)]
         frame = frames[0]
     else:
@@ -96,7 +99,7 @@ def main():
         gs.FrameIndex = k
         r.set_camera(cams[k % 8])
         r.set_constants(gs)
-        if world == 1:
+        if not tiled:
             r.render_device(frames[k % 2].data_ptr())
         else:
             r.render_tiles(packeds[k % 2].data_ptr())
@@ -106,7 +109,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if tiled:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -118,13 +121,13 @@ def main():
     for k in range(args.steps):
         step(args.warmup + k)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if tiled:
         dist.barrier()
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     tot = r.totals(reset=True)
     rays, paths = int(tot.rays), int(tot.paths)
-    if world > 1:
+    if tiled:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -152,7 +155,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.scene} sphere scene (seed 0, {len(spheres)} spheres), {w}x{h}, {args.spp} spp, {args.bounces} bounces, RR on, sky env"
-                            + (f", 32x32 tiles interleaved over {world} GPUs + RCCL gather to rank 0" if world > 1 else ""),
+                            + (f", 32x32 tiles interleaved over {world} GPU(s) + RCCL gather to rank 0" if tiled else ""),
+                "frames_in_flight": args.frames_in_flight,
                 "rays_per_frame": rays / args.steps,
                 "lbvh": {"nodes": int(accel.node_count), "depth": int(accel.depth), "lds_resident": bool(accel.lds_resident), "build_ms": float(accel.build_ms)},
             },
@@ -167,7 +171,7 @@ def main():
             gs.FrameIndex = args.warmup + k
             r.set_camera(cams[(args.warmup + k) % 8])
             r.set_constants(gs)
-            st = r.render_device(frame.data_ptr(), want_stats=True) if world == 1 else r.render_tiles(packed.data_ptr(), want_stats=True)
+            st = r.render_device(frame.data_ptr(), want_stats=True) if not tiled else r.render_tiles(packed.data_ptr(), want_stats=True)
             agg["ms_trav"] += st.ms_traverse
             agg["ms_shade"] += st.ms_shade
             agg["n_trav"] += st.traverse_launches
@@ -233,7 +237,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     r.close()
-    if world > 1:
+    if tiled:
         dist.destroy_process_group()
 
 

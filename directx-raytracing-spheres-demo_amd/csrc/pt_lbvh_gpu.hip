@@ -1,11 +1,311 @@
-// pt_lbvh_gpu.hip -- device LBVH builder.  (placeholder: the host builder is used until this lands)
+// pt_lbvh_gpu.hip -- device LBVH builder: bounds -> 30-bit Morton keys -> radix sort (hipCUB / rocPRIM) -> Karras 2012
+// radix tree -> bottom-up AABBs -> depth.  Produces exactly the tree of the host builder (pt_lbvh.cpp): every floating
+// point step is the same individually rounded fp32 operation, min/max are exact, and the keys are unique.
+// Replaces Scene::CreateAccelerationStructures (Source/Scene.ixx:225-284), which the reference re-runs every frame while
+// the physics is live (Source/App.cpp:605-608).
 #include "pt_lbvh_gpu.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <new>
 
 namespace pt {
 
-bool lbvh_gpu_available() { return false; }
-LbvhGpu* lbvh_gpu_create() { return nullptr; }
-void lbvh_gpu_destroy(LbvhGpu*) {}
-hipError_t lbvh_gpu_build(LbvhGpu*, const float4*, uint32_t, PtBvhNode*, float4*, uint32_t*, hipStream_t, LbvhGpuInfo*) { return hipErrorNotSupported; }
+namespace {
+
+// order-preserving float <-> uint mapping for atomicMin / atomicMax
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ord2f(uint32_t o)
+{
+    const uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+
+// header[0..2] centroid min, [3..5] centroid max, [6..8] bounds min, [9..11] bounds max (ordered uints), [12] depth
+constexpr int kHdrWords = 16;
+
+__global__ void init_header_kernel(uint32_t* hdr)
+{
+    const uint32_t i = threadIdx.x;
+    if (i < 12) hdr[i] = ((i / 3) & 1) ? 0u : 0xFFFFFFFFu;  // mins start at +max, maxes at 0
+    if (i == 12) hdr[12] = 0u;
+}
+
+__global__ void bounds_kernel(const float4* __restrict__ sph, uint32_t n, uint32_t* __restrict__ hdr)
+{
+    float cmin[3] = { INFINITY, INFINITY, INFINITY }, cmax[3] = { -INFINITY, -INFINITY, -INFINITY };
+    float bmin[3] = { INFINITY, INFINITY, INFINITY }, bmax[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 s = sph[i];
+        const float c[3] = { s.x, s.y, s.z };
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            cmin[a] = fminf(cmin[a], c[a]); cmax[a] = fmaxf(cmax[a], c[a]);
+            bmin[a] = fminf(bmin[a], c[a] - s.w); bmax[a] = fmaxf(bmax[a], c[a] + s.w);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            cmin[a] = fminf(cmin[a], __shfl_down(cmin[a], off, 64)); cmax[a] = fmaxf(cmax[a], __shfl_down(cmax[a], off, 64));
+            bmin[a] = fminf(bmin[a], __shfl_down(bmin[a], off, 64)); bmax[a] = fmaxf(bmax[a], __shfl_down(bmax[a], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            atomicMin(&hdr[0 + a], f2ord(cmin[a])); atomicMax(&hdr[3 + a], f2ord(cmax[a]));
+            atomicMin(&hdr[6 + a], f2ord(bmin[a])); atomicMax(&hdr[9 + a], f2ord(bmax[a]));
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t expand10(uint32_t v)
+{
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t quant10(float v)
+{
+    float s = v * 1024.0f;
+    s = s < 0.0f ? 0.0f : (s > 1023.0f ? 1023.0f : s);
+    return (uint32_t)s;
+}
+
+__global__ void morton_kernel(const float4* __restrict__ sph, uint32_t n, const uint32_t* __restrict__ hdr, unsigned long long* __restrict__ keys)
+{
+    float cmin[3], inv[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        cmin[a] = ord2f(hdr[a]);
+        const float e = ord2f(hdr[3 + a]) - cmin[a];
+        inv[a] = e > 0.0f ? 1.0f / e : 0.0f;
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 s = sph[i];
+        const uint32_t code = (expand10(quant10((s.x - cmin[0]) * inv[0])) << 2) | (expand10(quant10((s.y - cmin[1]) * inv[1])) << 1)
+                              | expand10(quant10((s.z - cmin[2]) * inv[2]));
+        keys[i] = ((unsigned long long)code << 32) | i;
+    }
+}
+
+__global__ void gather_kernel(const float4* __restrict__ sph, const unsigned long long* __restrict__ keys, uint32_t n, float4* __restrict__ sorted,
+                              uint32_t* __restrict__ sorted_id)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t id = (uint32_t)(keys[k] & 0xFFFFFFFFull);
+        sorted_id[k] = id;
+        sorted[k] = sph[id];
+    }
+}
+
+__device__ __forceinline__ int delta(const unsigned long long* __restrict__ keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long)(keys[i] ^ keys[j]));
+}
+
+// Karras 2012, one thread per internal node; also records each child's parent
+__global__ void hierarchy_kernel(const unsigned long long* __restrict__ keys, int n, PtBvhNode* __restrict__ nodes, int* __restrict__ leaf_parent)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n - 1; i += gridDim.x * blockDim.x) {
+        const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) > 0 ? 1 : -1;
+        const int dmin = delta(keys, n, i, i - d);
+        int lmax = 2;
+        while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+        int l = 0;
+        for (int t = lmax / 2; t >= 1; t /= 2)
+            if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+        const int j = i + l * d;
+        const int dnode = delta(keys, n, i, j);
+        int s = 0;
+        for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+            if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+            if (t == 1) break;
+        }
+        const int gamma = i + s * d + min(d, 0);
+        const int lo = min(i, j), hi = max(i, j);
+        const int c0 = (lo == gamma) ? ~gamma : gamma;
+        const int c1 = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+        nodes[i].child0 = c0;
+        nodes[i].child1 = c1;
+        nodes[i]._pad = 0;
+        if (i == 0) nodes[0].parent = -1;
+        if (c0 >= 0) nodes[c0].parent = i; else leaf_parent[~c0] = i;
+        if (c1 >= 0) nodes[c1].parent = i; else leaf_parent[~c1] = i;
+    }
+}
+
+// Bottom-up AABBs: one thread per leaf climbs; at every node the first arriver stops, the second (which then sees both
+// child boxes) continues.  Child boxes are stored in the parent (PtBvhNode layout).  Also tracks the leaf depth.
+__global__ void refit_kernel(const float4* __restrict__ sorted, int n, PtBvhNode* __restrict__ nodes, const int* __restrict__ leaf_parent,
+                             uint32_t* __restrict__ flags, const uint32_t* __restrict__ hdr_ro)
+{
+    // padding = 2^-17 * max |coordinate| of the scene bounds (lbvh_padding in pt_lbvh.cpp)
+    float smax = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) smax = fmaxf(smax, fmaxf(fabsf(ord2f(hdr_ro[6 + a])), fabsf(ord2f(hdr_ro[9 + a]))));
+    const float pad = smax * 7.62939453125e-06f;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const float4 s = sorted[k];
+        float lo[3] = { s.x - s.w - pad, s.y - s.w - pad, s.z - s.w - pad };
+        float hi[3] = { s.x + s.w + pad, s.y + s.w + pad, s.z + s.w + pad };
+        int child = ~k;
+        int p = leaf_parent[k];
+        while (p >= 0) {
+            PtBvhNode* nd = &nodes[p];
+            const bool slot0 = nd->child0 == child;
+            float* dlo = slot0 ? nd->lo0 : nd->lo1;
+            float* dhi = slot0 ? nd->hi0 : nd->hi1;
+#pragma unroll
+            for (int a = 0; a < 3; a++) { dlo[a] = lo[a]; dhi[a] = hi[a]; }
+            // release: publish this child's box before announcing arrival (agent scope; the explicit wait keeps the
+            // write-back ahead of the atomic -- see cdna_hip_programming.md Guideline 16, compiler hazard)
+            __threadfence();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (atomicAdd(&flags[p], 1u) == 0u) break;  // first to arrive: the sibling's thread continues
+            __threadfence();  // acquire: the sibling's box was written from another CU, possibly another XCD
+            const volatile float* olo = slot0 ? nd->lo1 : nd->lo0;
+            const volatile float* ohi = slot0 ? nd->hi1 : nd->hi0;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                lo[a] = fminf(lo[a], olo[a]);
+                hi[a] = fmaxf(hi[a], ohi[a]);
+            }
+            child = p;
+            p = nd->parent;
+        }
+    }
+}
+
+__global__ void depth_kernel(const PtBvhNode* __restrict__ nodes, const int* __restrict__ leaf_parent, int n, uint32_t* __restrict__ hdr)
+{
+    uint32_t best = 0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        uint32_t d = 0;
+        for (int p = leaf_parent[k]; p >= 0; p = nodes[p].parent) d++;
+        best = max(best, d);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = max(best, (uint32_t)__shfl_down(best, off, 64));
+    if ((threadIdx.x & 63u) == 0 && best) atomicMax(&hdr[12], best);
+}
+
+}  // namespace
+
+struct LbvhGpu {
+    unsigned long long* keys_in = nullptr;
+    unsigned long long* keys_out = nullptr;
+    int* leaf_parent = nullptr;
+    uint32_t* flags = nullptr;
+    uint32_t* hdr = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    size_t cap = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
+bool lbvh_gpu_available() { return true; }
+
+LbvhGpu* lbvh_gpu_create()
+{
+    LbvhGpu* b = new (std::nothrow) LbvhGpu();
+    if (!b) return nullptr;
+    if (hipMalloc(&b->hdr, kHdrWords * sizeof(uint32_t)) != hipSuccess || hipEventCreate(&b->e0) != hipSuccess || hipEventCreate(&b->e1) != hipSuccess) {
+        lbvh_gpu_destroy(b);
+        return nullptr;
+    }
+    return b;
+}
+
+static void free_buffers(LbvhGpu* b)
+{
+    if (b->keys_in) (void)hipFree(b->keys_in);
+    if (b->keys_out) (void)hipFree(b->keys_out);
+    if (b->leaf_parent) (void)hipFree(b->leaf_parent);
+    if (b->flags) (void)hipFree(b->flags);
+    if (b->sort_tmp) (void)hipFree(b->sort_tmp);
+    b->keys_in = b->keys_out = nullptr; b->leaf_parent = nullptr; b->flags = nullptr; b->sort_tmp = nullptr;
+    b->cap = 0; b->sort_tmp_bytes = 0;
+}
+
+void lbvh_gpu_destroy(LbvhGpu* b)
+{
+    if (!b) return;
+    free_buffers(b);
+    if (b->hdr) (void)hipFree(b->hdr);
+    if (b->e0) (void)hipEventDestroy(b->e0);
+    if (b->e1) (void)hipEventDestroy(b->e1);
+    delete b;
+}
+
+#define LB_CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t lbvh_gpu_build(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode* d_nodes, float4* d_sorted, uint32_t* d_sorted_id,
+                          hipStream_t stream, LbvhGpuInfo* info)
+{
+    if (!b || !d_sph || n == 0 || !d_sorted || !d_sorted_id || !info) return hipErrorInvalidValue;
+    if (n > b->cap) {
+        LB_CK(hipStreamSynchronize(stream));
+        free_buffers(b);
+        LB_CK(hipMalloc(&b->keys_in, (size_t)n * sizeof(unsigned long long)));
+        LB_CK(hipMalloc(&b->keys_out, (size_t)n * sizeof(unsigned long long)));
+        LB_CK(hipMalloc(&b->leaf_parent, (size_t)n * sizeof(int)));
+        LB_CK(hipMalloc(&b->flags, (size_t)n * sizeof(uint32_t)));
+        size_t tmp = 0;
+        LB_CK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, b->keys_in, b->keys_out, (int)n, 0, 62, stream));
+        LB_CK(hipMalloc(&b->sort_tmp, tmp ? tmp : 16));
+        b->sort_tmp_bytes = tmp;
+        b->cap = n;
+    }
+    const uint32_t threads = 256;
+    const uint32_t grid = (n + threads - 1) / threads < 4096u ? (n + threads - 1) / threads : 4096u;
+    LB_CK(hipEventRecord(b->e0, stream));
+    hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, stream, b->hdr);
+    hipLaunchKernelGGL(bounds_kernel, dim3(grid), dim3(threads), 0, stream, d_sph, n, b->hdr);
+    hipLaunchKernelGGL(morton_kernel, dim3(grid), dim3(threads), 0, stream, d_sph, n, b->hdr, b->keys_in);
+    size_t tmp = b->sort_tmp_bytes;
+    LB_CK(hipcub::DeviceRadixSort::SortKeys(b->sort_tmp, tmp, b->keys_in, b->keys_out, (int)n, 0, 62, stream));
+    hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(threads), 0, stream, d_sph, b->keys_out, n, d_sorted, d_sorted_id);
+    if (n > 1) {
+        LB_CK(hipMemsetAsync(b->flags, 0, (size_t)n * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(hierarchy_kernel, dim3(grid), dim3(threads), 0, stream, b->keys_out, (int)n, d_nodes, b->leaf_parent);
+        hipLaunchKernelGGL(refit_kernel, dim3(grid), dim3(threads), 0, stream, d_sorted, (int)n, d_nodes, b->leaf_parent, b->flags, b->hdr);
+        hipLaunchKernelGGL(depth_kernel, dim3(grid), dim3(threads), 0, stream, d_nodes, b->leaf_parent, (int)n, b->hdr);
+    }
+    LB_CK(hipGetLastError());
+    LB_CK(hipEventRecord(b->e1, stream));
+    uint32_t hdr[kHdrWords];
+    LB_CK(hipMemcpyAsync(hdr, b->hdr, sizeof hdr, hipMemcpyDeviceToHost, stream));
+    LB_CK(hipStreamSynchronize(stream));
+    float ms = 0;
+    LB_CK(hipEventElapsedTime(&ms, b->e0, b->e1));
+    info->build_ms = ms;
+    info->depth = n > 1 ? hdr[12] : 0u;
+    float smax = 0.0f;
+    for (int a = 0; a < 3; a++) {
+        info->bounds_min[a] = ord2f(hdr[6 + a]);
+        info->bounds_max[a] = ord2f(hdr[9 + a]);
+        smax = std::fmax(smax, std::fmax(std::fabs(info->bounds_min[a]), std::fabs(info->bounds_max[a])));
+    }
+    info->pad = smax * 7.62939453125e-06f;
+    return hipSuccess;
+}
 
 }  // namespace pt

@@ -81,7 +81,7 @@ def candidates(spheres, o, d):
     return dist2 <= rr * rr
 
 
-@pytest.mark.parametrize("name,count", [("small", 0), ("demo", 0), ("procedural", 50000)])
+@pytest.mark.parametrize("name,count", [("small", 0), ("demo", 0), ("procedural", 50000), ("procedural", 1 << 20)])
 def test_device_tree_structure(dxrs, host, name, count):
     kind = {"small": dxrs.host.SCENE_SMALL, "demo": dxrs.host.SCENE_DEMO, "procedural": dxrs.host.SCENE_PROCEDURAL}[name]
     spheres, materials, sd = host.scene(kind, seed=1, count=count)
@@ -89,13 +89,15 @@ def test_device_tree_structure(dxrs, host, name, count):
     try:
         info = r.set_scene(spheres, materials, sd)
         nodes, order = r.download_accel()
-        check_lbvh(spheres, nodes, order, info.depth)
+        if len(spheres) <= 100000:  # the Python invariant walk is O(n) with numpy per node: minutes at 2^20
+            check_lbvh(spheres, nodes, order, info.depth)
         if name != "procedural":
             assert info.lds_resident == 1  # small scenes: whole BVH staged in LDS
         # the device tree is the same tree the host builder produces
         hn, ho, hd = dxrs.load_hip().lbvh_build_host(spheres)
         assert hd == info.depth and np.array_equal(ho, order)
-        assert np.array_equal(hn["child0"], nodes["child0"]) and np.array_equal(hn["child1"], nodes["child1"])
+        for f in ("child0", "child1", "parent", "lo0", "hi0", "lo1", "hi1"):
+            assert np.array_equal(hn[f], nodes[f]), f  # device build == host build, boxes bit-for-bit
     finally:
         r.close()
 
