@@ -14,12 +14,17 @@ struct Bsdf {
     f3 BaseColor;
     float Metallic;
     f3 Albedo;
-    float Roughness, IORi, IORo;
+    float Roughness, IORi, IORo, Eta;
     f3 F0;
     float Transmission;
 };
 
-PT_HD Bsdf bsdf_init(f3 base, float metallic, float roughness, float ior, float transmission, bool front)
+// F0 of the dielectric interface: ((IORi - IORo) / (IORi + IORo))^2 is the same for both orientations (the quotient only
+// changes sign), so it is a per-material constant; pt_set_scene stores it (and 1/IOR) in the material's padding words.
+PT_HD float dielectric_f0(float ior) { float r = (1.0f - ior) / (1.0f + ior); return r * r; }
+
+// f0d = dielectric_f0(ior) and inv_ior = 1/ior may be precomputed per material (bit-identical to computing them here)
+PT_HD Bsdf bsdf_init_pre(f3 base, float metallic, float roughness, float ior, float inv_ior, float f0d, float transmission, bool front)
 {
     Bsdf b;
     b.BaseColor = base;
@@ -28,11 +33,16 @@ PT_HD Bsdf bsdf_init(f3 base, float metallic, float roughness, float ior, float 
     b.Roughness = pt_max(kMinRoughness, roughness);
     b.IORi = front ? 1.0f : ior;
     b.IORo = front ? ior : 1.0f;
-    float r = (b.IORi - b.IORo) / (b.IORi + b.IORo);
-    float f0d = r * r;  // pow(x, 2) of BxDF.hlsli:64 restated as x*x
+    b.Eta = front ? inv_ior : ior;  // IORi / IORo: 1/ior, or ior/1 = ior exactly
+    // lerp(f0d, baseColor, metallic), f0d = pow((IORi - IORo) / (IORi + IORo), 2) of BxDF.hlsli:64 restated as x*x
     b.F0 = make_f3(pt_fma(metallic, base.x - f0d, f0d), pt_fma(metallic, base.y - f0d, f0d), pt_fma(metallic, base.z - f0d, f0d));
     b.Transmission = transmission;
     return b;
+}
+
+PT_HD Bsdf bsdf_init(f3 base, float metallic, float roughness, float ior, float transmission, bool front)
+{
+    return bsdf_init_pre(base, metallic, roughness, ior, 1.0f / ior, dielectric_f0(ior), transmission, front);
 }
 
 // SurfaceVectors (SurfaceVectors.hlsli:5-15)
@@ -101,7 +111,7 @@ PT_HD bool bsdf_sample(const Bsdf& b, const Surf& s, f3 V, const float w[3], con
         return dot(s.FrontNg, L) > 0.0f;
     }
     float voh = pt_abs(dot(V, H));
-    float eta = b.IORi / b.IORo;
+    float eta = b.Eta;
     if (eta * eta * (1.0f - voh * voh) > 1.0f || rnd[3] < fresnel_dielectric(eta, voh)) {
         L = reflect(-V, H);
     } else {
@@ -175,9 +185,12 @@ PT_HD f3 bsdf_eval(const Bsdf& b, const Surf& s, f3 L, f3 V, const float w[3], i
 struct CameraParams {
     f3 Position, Right, Up, Forward;
     float Near, Far, JitterX, JitterY;
+    // per-frame constants hoisted out of the per-pixel code (computed once on the host with the same arithmetic)
+    f3 ForwardN;        // normalize(Forward) of GeneratePinholeRay
+    float InvW, InvH;   // 1 / RenderSize of CalculateUV
 };
 
-PT_HD CameraParams camera_params(const PtCamera& c)
+PT_HD CameraParams camera_params(const PtCamera& c, uint32_t w, uint32_t h)
 {
     CameraParams p;
     p.Position = make_f3(c.Position[0], c.Position[1], c.Position[2]);
@@ -185,19 +198,21 @@ PT_HD CameraParams camera_params(const PtCamera& c)
     p.Up = make_f3(c.UpDirection[0], c.UpDirection[1], c.UpDirection[2]);
     p.Forward = make_f3(c.ForwardDirection[0], c.ForwardDirection[1], c.ForwardDirection[2]);
     p.Near = c.NearDepth; p.Far = c.FarDepth; p.JitterX = c.Jitter[0]; p.JitterY = c.Jitter[1];
+    p.ForwardN = normalize(p.Forward);
+    p.InvW = 1.0f / (float)w;
+    p.InvH = 1.0f / (float)h;
     return p;
 }
 
-PT_HD void primary_ray(const CameraParams& cam, uint32_t px, uint32_t py, uint32_t w, uint32_t h,
-                       f3& o, f3& d, float& tmin, float& tmax)
+PT_HD void primary_ray(const CameraParams& cam, uint32_t px, uint32_t py, f3& o, f3& d, float& tmin, float& tmax)
 {
-    float u = ((float)px + 0.5f + cam.JitterX) / (float)w;
-    float v = ((float)py + 0.5f + cam.JitterY) / (float)h;
+    float u = ((float)px + 0.5f + cam.JitterX) * cam.InvW;
+    float v = ((float)py + 0.5f + cam.JitterY) * cam.InvH;
     float nx = pt_fma(u, 2.0f, -1.0f);
     float ny = pt_fma(v, -2.0f, 1.0f);
     f3 dir = mad(ny, cam.Up, cam.Right * nx) + cam.Forward;
     dir = normalize(dir);
-    float inv_cos = 1.0f / dot(normalize(cam.Forward), dir);
+    float inv_cos = 1.0f / dot(cam.ForwardN, dir);
     o = cam.Position;
     d = dir;
     tmin = cam.Near * inv_cos;

@@ -94,6 +94,7 @@ struct FrameParams {
     CameraParams cam;
     uint32_t frame_index, bounces, spp, rr_enabled;
     float throughput_threshold;
+    float inv_spp;  // 1 / (float)spp
 };
 
 // Per-frame device counters, double buffered by frame parity so that the first kernel of a frame can append to this

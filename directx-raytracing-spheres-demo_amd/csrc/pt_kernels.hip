@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kTraverseThreads) void primary_kernel(SceneView sv,
         uint32_t rng = 0;
         if (pr.valid) {
             float tmin, tmax;
-            primary_ray(fp.cam, pr.px, pr.py, pm.img_w, pm.img_h, o, d, tmin, tmax);
+            primary_ray(fp.cam, pr.px, pr.py, o, d, tmin, tmax);
             rng = rng_init(pr.px, pr.py, fp.frame_index);
             closest_hit<StackT>(nodes, sph, ids, sv.n, o, d, tmin, tmax, stack, blockDim.x, t, id);
         } else if (pm.mode == 1) {
@@ -268,12 +268,13 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
             end_sample = true;
         } else {
             const float4 sp = sv.sph[id];
-            const float4 m0 = sv.mats[id * 4 + 0], m1 = sv.mats[id * 4 + 1], m2 = sv.mats[id * 4 + 2];
+            const float4 m0 = sv.mats[id * 4 + 0], m1 = sv.mats[id * 4 + 1], m2 = sv.mats[id * 4 + 2], m3 = sv.mats[id * 4 + 3];
             hf = hit_frame(ps.o, ps.d, t, load3(sp), sp.w);
             const f3 emission = make_f3(m1.y, m1.z, m1.w) * m1.x;  // Material::GetEmission
             // bounce 0 mirrors the G-buffer round trip: Transmission = Metallic < 1 ? Transmission : 0 (Raytracing.hlsl:148)
             const float transmission = (ps.bounce == 0 && !(m2.x < 1.0f)) ? 0.0f : m2.w;
-            const Bsdf bsdf = bsdf_init(load3(m0), m2.x, m2.y, m2.z, transmission, hf.front);
+            // m3.z / m3.w: dielectric F0 and 1/IOR, precomputed per material by pt_set_scene (padding words of PtMaterial)
+            const Bsdf bsdf = bsdf_init_pre(load3(m0), m2.x, m2.y, m2.z, m3.w, m3.z, transmission, hf.front);
             const bool t_finite = is_finite(ps.T.x) && is_finite(ps.T.y) && is_finite(ps.T.z);
             if (emission.x != 0.0f || emission.y != 0.0f || emission.z != 0.0f || !t_finite) {
                 if (ps.dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
@@ -304,11 +305,11 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
                         if (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) {
                             end_sample = true;
                         } else {
-                            ps.T = ps.T * make_f3(f.x / pdf, f.y / pdf, f.z / pdf);  // :346
+                            { const float inv_pdf = 1.0f / pdf; ps.T = ps.T * (f * inv_pdf); }  // :346
                             if (fp.rr_enabled && ps.bounce > 3) {                     // :348-356
                                 const float p = pt_max(ps.T.x, pt_max(ps.T.y, ps.T.z));
                                 if (rng_float(ps.rng) >= p) end_sample = true;
-                                else ps.T = make_f3(ps.T.x / p, ps.T.y / p, ps.T.z / p);
+                                else ps.T = ps.T * (1.0f / p);
                             }
                             if (!end_sample && luminance(ps.T) <= fp.throughput_threshold) end_sample = true;  // :361
                             if (last) end_sample = true;
@@ -336,8 +337,7 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
         if (ps.sample == fp.spp) {  // :378-385
             f3 res = make_f3(0.f, 0.f, 0.f);
             if (is_finite(total.x) && is_finite(total.y) && is_finite(total.z)) {
-                const float fs = (float)fp.spp;
-                res = make_f3(total.x / fs, total.y / fs, total.z / fs);
+                res = total * fp.inv_spp;
             }
             out[pr.out_index] = make_float4(res.x, res.y, res.z, 1.0f);
             return false;
@@ -345,7 +345,7 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
         scratch.radiance[slot] = make_float4(total.x, total.y, total.z, 0.f);
         // ---- regenerate: every sample restarts from the same primary ray / primary hit (:193-198)
         float tmin, tmax;
-        primary_ray(fp.cam, pr.px, pr.py, pm.img_w, pm.img_h, ps.o, ps.d, tmin, tmax);
+        primary_ray(fp.cam, pr.px, pr.py, ps.o, ps.d, tmin, tmax);
         const uint2 ph = scratch.primary_hit[slot];
         t = as_float(ph.x);
         id = ph.y;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kFusedThreads) void bounce_kernel(SceneView sv, Pix
                 ps.T = make_f3(1.f, 1.f, 1.f);
                 ps.o = make_f3(0.f, 0.f, 0.f); ps.d = make_f3(0.f, 0.f, 1.f);
                 if (live) {
-                    primary_ray(fp.cam, pr.px, pr.py, pm.img_w, pm.img_h, ps.o, ps.d, tmin, tmax);
+                    primary_ray(fp.cam, pr.px, pr.py, ps.o, ps.d, tmin, tmax);
                     ps.rng = rng_init(pr.px, pr.py, fp.frame_index);
                 } else if (pm.mode == 1) {
                     out[pr.out_index] = make_float4(0.f, 0.f, 0.f, 0.f);  // padding pixel of an edge tile

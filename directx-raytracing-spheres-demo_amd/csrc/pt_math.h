@@ -124,8 +124,8 @@ PT_HD float pow_spec(float x, float y) { return exp2_spec(y * log2_spec(x)); }
 PT_HD float from_srgb(float c)
 {
     c = saturate(c);
-    if (c <= 0.04045f) return c / 12.92f;
-    return pow_spec((c + 0.055f) / 1.055f, 2.4f);
+    if (c <= 0.04045f) return c * (1.0f / 12.92f);
+    return pow_spec((c + 0.055f) * (1.0f / 1.055f), 2.4f);
 }
 
 // Color::Luminance
@@ -196,7 +196,7 @@ PT_HD float distribution_term(float roughness, float noh)
     float m2 = m * m;
     float t = pt_fma(-(noh * noh), 0.99999994f - m2, 1.0f);
     float a = pt_max(m, 1e-6f) / t;
-    return (a * a) / kPi;
+    return (a * a) * kInvPi;
 }
 
 PT_HD float vndf_pdf(f3 Vl, float noh, float roughness)
@@ -204,9 +204,8 @@ PT_HD float vndf_pdf(f3 Vl, float noh, float roughness)
     float m = roughness * roughness;
     float m2 = m * m;
     float nov = pt_abs(Vl.z);
-    float g1 = (2.0f * nov) / (nov + pt_sqrt(pt_fma(1.0f - m2, nov * nov, m2)));
     float d = distribution_term(roughness, noh);
-    return d * g1 / (4.0f * nov);
+    return d * (0.5f / (nov + pt_sqrt(pt_fma(1.0f - m2, nov * nov, m2))));  // D G1 / (4 NoV), one division
 }
 
 PT_HD float geometry_term_mod(float roughness, float nol, float nov)
@@ -267,8 +266,8 @@ PT_HD f3 environment_color(float er, float eg, float eb, float ea, f3 d)
 {
     if (ea >= 0.0f) return make_f3(er, eg, eb);
     float t = (d.y + 1.0f) * 0.5f;
-    float r = pt_fma(t, 0.5f - 1.0f, 1.0f), g = pt_fma(t, 0.7f - 1.0f, 1.0f), b = pt_fma(t, 1.0f - 1.0f, 1.0f);
-    return make_f3(from_srgb(r), from_srgb(g), from_srgb(b));
+    float r = pt_fma(t, 0.5f - 1.0f, 1.0f), g = pt_fma(t, 0.7f - 1.0f, 1.0f);
+    return make_f3(from_srgb(r), from_srgb(g), 1.0f);  // blue: lerp(1,1,t) = 1 and FromSrgb(1) = 1 exactly
 }
 
 // ---------------------------------------------------------------- ray-sphere (replaces CastRay's triangle hit, RaytracingHelpers.hlsli:57-133)

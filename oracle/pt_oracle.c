@@ -146,8 +146,8 @@ float oracle_pow(float x, float y) { return oracle_exp2(y * oracle_log2(x)); }
 float oracle_from_srgb(float c)
 {
     c = f_sat(c);
-    if (c <= 0.04045f) return c / 12.92f;
-    return oracle_pow((c + 0.055f) / 1.055f, 2.4f);
+    if (c <= 0.04045f) return c * (1.0f / 12.92f);
+    return oracle_pow((c + 0.055f) * (1.0f / 1.055f), 2.4f);
 }
 
 static inline float luminance(v3 c) { return v_dot(c, V3(0.2126f, 0.7152f, 0.0722f)); }
@@ -235,7 +235,7 @@ float oracle_distribution_term(float roughness, float noh)
     float m2 = m * m;
     float t = FMA(-(noh * noh), 0.99999994f - m2, 1.0f);
     float a = f_max(m, 1e-6f) / t;
-    return (a * a) / PT_PI;
+    return (a * a) * PT_INV_PI;
 }
 /* VNDF::GetPDF(Vlocal, NoH, roughness) = D * G1(|Vl.z|) / (4 |Vl.z|) */
 float oracle_vndf_pdf(const float vl[3], float noh, float roughness)
@@ -243,9 +243,9 @@ float oracle_vndf_pdf(const float vl[3], float noh, float roughness)
     float m = roughness * roughness;
     float m2 = m * m;
     float nov = f_abs(vl[2]);
-    float g1 = (2.0f * nov) / (nov + sqrtf(FMA(1.0f - m2, nov * nov, m2)));
+    /* D * G1 / (4 NoV) with G1 = 2 NoV / (NoV + sqrt(m2 + (1 - m2) NoV^2)), simplified to one division */
     float d = oracle_distribution_term(roughness, noh);
-    return d * g1 / (4.0f * nov);
+    return d * (0.5f / (nov + sqrtf(FMA(1.0f - m2, nov * nov, m2))));
 }
 /* BRDF::GeometryTermMod (Smith height-correlated / (4 NoL NoV)) */
 float oracle_geometry_term_mod(float roughness, float nol, float nov)
@@ -313,8 +313,9 @@ static v3 environment_color(const PtSceneData *sd, v3 d)
         return V3(sd->EnvironmentLightColor[0], sd->EnvironmentLightColor[1], sd->EnvironmentLightColor[2]);
     float t = (d.y + 1.0f) * 0.5f;
     /* lerp(1, (0.5,0.7,1), t) = 1 + t*(b-1) */
-    float r = FMA(t, 0.5f - 1.0f, 1.0f), g = FMA(t, 0.7f - 1.0f, 1.0f), b = FMA(t, 1.0f - 1.0f, 1.0f);
-    return V3(oracle_from_srgb(r), oracle_from_srgb(g), oracle_from_srgb(b));
+    float r = FMA(t, 0.5f - 1.0f, 1.0f), g = FMA(t, 0.7f - 1.0f, 1.0f);
+    /* blue: lerp(1, 1, t) = fma(t, 0, 1) = 1 and FromSrgb(1) = 1 exactly (tests/test_oracle_kat.py) */
+    return V3(oracle_from_srgb(r), oracle_from_srgb(g), 1.0f);
 }
 void oracle_sky(const PtSceneData *scene, const float dir[3], float out[3])
 {
@@ -411,8 +412,9 @@ void oracle_spawn_origin(const float P[3], const float N[3], float offset, const
 static void primary_ray(const PtCamera *cam, uint32_t px, uint32_t py, uint32_t w, uint32_t h,
                         v3 *o, v3 *d, float *tmin, float *tmax)
 {
-    float u = ((float)px + 0.5f + cam->Jitter[0]) / (float)w;
-    float v = ((float)py + 0.5f + cam->Jitter[1]) / (float)h;
+    float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
+    float u = ((float)px + 0.5f + cam->Jitter[0]) * inv_w;
+    float v = ((float)py + 0.5f + cam->Jitter[1]) * inv_h;
     float nx = FMA(u, 2.0f, -1.0f);
     float ny = FMA(v, -2.0f, 1.0f);
     v3 R = V3(cam->RightDirection[0], cam->RightDirection[1], cam->RightDirection[2]);
@@ -698,11 +700,11 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
             if (pdf == 0.0f) { trace_event(tr, s, bnc, &hit, 1, L, T, rng, lobe, 4); break; }
             v3 f = bsdf_eval(&bsdf, &sv, L, V, w, lobe); /* :341 */
             if (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) { trace_event(tr, s, bnc, &hit, 1, L, T, rng, lobe, 5); break; }
-            T = v_mul(T, V3(f.x / pdf, f.y / pdf, f.z / pdf)); /* :346 */
+            { float inv_pdf = 1.0f / pdf; T = v_mul(T, v_scale(f, inv_pdf)); } /* :346 */
             if (gs->IsRussianRouletteEnabled && bnc > 3) { /* :348-356 */
                 float p = f_max(T.x, f_max(T.y, T.z));
                 if (oracle_rng_float(&rng) >= p) { trace_event(tr, s, bnc, &hit, 1, L, T, rng, lobe, 6); break; }
-                T = V3(T.x / p, T.y / p, T.z / p);
+                T = v_scale(T, 1.0f / p);
             }
             if (luminance(T) <= gs->ThroughputThreshold) { trace_event(tr, s, bnc, &hit, 1, L, T, rng, lobe, 7); break; } /* :361 */
             trace_event(tr, s, bnc, &hit, 1, L, T, rng, lobe, 0);
@@ -710,8 +712,7 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
         radiance = v_add(radiance, sample_radiance); /* :373 */
     }
     if (f_finite(radiance.x) && f_finite(radiance.y) && f_finite(radiance.z)) { /* :378 */
-        float fs = (float)spp;
-        radiance = V3(radiance.x / fs, radiance.y / fs, radiance.z / fs);
+        radiance = v_scale(radiance, 1.0f / (float)spp);
     } else {
         radiance = V3(0, 0, 0);
     }

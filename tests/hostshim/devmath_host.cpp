@@ -58,7 +58,7 @@ void dev_spawn_origin(const float P[3], const float N[3], float offset, const fl
 void dev_primary_ray(const PtCamera* cam, uint32_t px, uint32_t py, uint32_t w, uint32_t h, float o[3], float d[3], float* tmin, float* tmax)
 {
     f3 oo, dd;
-    primary_ray(camera_params(*cam), px, py, w, h, oo, dd, *tmin, *tmax);
+    primary_ray(camera_params(*cam, w, h), px, py, oo, dd, *tmin, *tmax);
     o[0] = oo.x; o[1] = oo.y; o[2] = oo.z; d[0] = dd.x; d[1] = dd.y; d[2] = dd.z;
 }
 
