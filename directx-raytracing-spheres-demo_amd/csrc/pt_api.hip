@@ -493,7 +493,7 @@ PtStatus pt_create(const PtConfig* config, PtContext** out_ctx)
     c->device = config->device;
     c->flags = config->flags;
     c->tile_size = config->tile_size ? config->tile_size : 32;
-    if (c->tile_size % 8 != 0 || c->tile_size > 1024) { delete c; return PT_ERR_INVALID_ARG; }
+    if (c->tile_size < 8 || c->tile_size > 1024 || (c->tile_size & (c->tile_size - 1)) != 0) { delete c; return PT_ERR_INVALID_ARG; }  // power of two
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return PT_ERR_HIP; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = (uint32_t)prop.multiProcessorCount;
@@ -694,7 +694,9 @@ PtStatus pt_render(PtContext* c, const PtRect* rect, void* out, int out_is_devic
     pm.img_w = c->gs.RenderSize[0]; pm.img_h = c->gs.RenderSize[1];
     pm.rx = r.x; pm.ry = r.y; pm.rw = r.w; pm.rh = r.h;
     pm.blocks_x = (r.w + 7) / 8;
+    pm.inv_blocks_x = 1.0f / (float)pm.blocks_x;
     const uint64_t slots = (uint64_t)pm.blocks_x * ((r.h + 7) / 8) * 64ull;
+    pm.exact_div = (slots >> 6) >= (1ull << 22) ? 1u : 0u;  // quotient estimate error stays below one
     if (slots > 0xFFFFFFFFull) return fail(c, PT_ERR_INVALID_ARG, "pt_render: rect too large");
     pm.n_slots = (uint32_t)slots;
     float4* dev_out = static_cast<float4*>(out);
@@ -729,7 +731,9 @@ PtStatus pt_render_tiles(PtContext* c, void* out_device_packed, PtStats* stats)
     pm.mode = 1;
     pm.img_w = w; pm.img_h = h;
     pm.ts = ts;
+    pm.ts_shift = (uint32_t)__builtin_ctz(ts);
     pm.tiles_x = (w + ts - 1) / ts;
+    pm.inv_tiles_x = 1.0f / (float)pm.tiles_x;
     pm.tiles_total = pm.tiles_x * ((h + ts - 1) / ts);
     pm.rank = c->rank; pm.world = c->world;
     const uint64_t slots = (uint64_t)pt_tiles_count(c, c->rank) * ts * ts;

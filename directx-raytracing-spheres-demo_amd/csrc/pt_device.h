@@ -52,8 +52,11 @@ struct PixelMap {
     uint32_t img_w, img_h;        // RenderSize
     uint32_t rx, ry, rw, rh;      // rect (mode 0)
     uint32_t blocks_x;            // ceil(rw / 8) (mode 0)
-    uint32_t ts, tiles_x, tiles_total, rank, world;  // mode 1
+    uint32_t ts, tiles_x, tiles_total, rank, world;  // mode 1 (ts = 1 << ts_shift)
+    uint32_t ts_shift;
     uint32_t n_slots;
+    float inv_blocks_x, inv_tiles_x;  // reciprocals for fast_div
+    uint32_t exact_div;               // 1: slot counts too large for the float-reciprocal division
 };
 
 struct PixelRef {
@@ -62,30 +65,42 @@ struct PixelRef {
     bool valid;
 };
 
+// n / d for a launch-invariant divisor: float reciprocal + one exact correction step.  Valid while n < 2^22 (the float
+// conversion is exact and the quotient estimate is off by at most one); PixelMap::exact_div selects the plain division
+// for larger slot counts.  A 32-bit integer division costs ~25 VALU instructions on gfx950, this ~8.
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t d, float inv_d, bool exact_div)
+{
+    if (exact_div) return n / d;
+    uint32_t q = (uint32_t)((float)n * inv_d);
+    const int32_t r = (int32_t)(n - q * d);
+    if (r < 0) q--; else if ((uint32_t)r >= d) q++;
+    return q;
+}
+
 __device__ __forceinline__ PixelRef slot_to_pixel(const PixelMap& m, uint32_t slot)
 {
     PixelRef r;
     if (m.mode == 0) {
-        uint32_t b = slot >> 6, l = slot & 63u;
-        uint32_t bx = b % m.blocks_x, by = b / m.blocks_x;
-        uint32_t x = bx * 8u + (l & 7u), y = by * 8u + (l >> 3);
+        const uint32_t b = slot >> 6, l = slot & 63u;
+        const uint32_t by = fast_div(b, m.blocks_x, m.inv_blocks_x, m.exact_div != 0), bx = b - by * m.blocks_x;
+        const uint32_t x = bx * 8u + (l & 7u), y = by * 8u + (l >> 3);
         r.valid = x < m.rw && y < m.rh;
         r.px = m.rx + x;
         r.py = m.ry + y;
         r.out_index = y * m.rw + x;
     } else {
-        uint32_t ts2 = m.ts * m.ts;
-        uint32_t k = slot / ts2, w = slot - k * ts2;
-        // 8x8 blocks inside the tile so a wave stays coherent
-        uint32_t bpt = m.ts >> 3;  // blocks per tile row
-        uint32_t b = w >> 6, l = w & 63u;
-        uint32_t lx = (b % bpt) * 8u + (l & 7u), ly = (b / bpt) * 8u + (l >> 3);
-        uint32_t gt = m.rank + k * m.world;
-        uint32_t tx = gt % m.tiles_x, ty = gt / m.tiles_x;
-        r.px = tx * m.ts + lx;
-        r.py = ty * m.ts + ly;
+        // tile edge ts is a power of two >= 8 (ts_shift = log2 ts): shifts and masks only, except the tile -> (tx, ty) split
+        const uint32_t ts2_shift = 2u * m.ts_shift;
+        const uint32_t k = slot >> ts2_shift, w = slot & ((1u << ts2_shift) - 1u);
+        const uint32_t bpt_shift = m.ts_shift - 3u;  // 8x8 blocks per tile row = ts / 8
+        const uint32_t b = w >> 6, l = w & 63u;
+        const uint32_t lx = ((b & ((1u << bpt_shift) - 1u)) << 3) + (l & 7u), ly = ((b >> bpt_shift) << 3) + (l >> 3);
+        const uint32_t gt = m.rank + k * m.world;
+        const uint32_t ty = fast_div(gt, m.tiles_x, m.inv_tiles_x, m.exact_div != 0), tx = gt - ty * m.tiles_x;
+        r.px = (tx << m.ts_shift) + lx;
+        r.py = (ty << m.ts_shift) + ly;
         r.valid = gt < m.tiles_total && r.px < m.img_w && r.py < m.img_h;
-        r.out_index = k * ts2 + ly * m.ts + lx;
+        r.out_index = (k << ts2_shift) + (ly << m.ts_shift) + lx;
     }
     return r;
 }

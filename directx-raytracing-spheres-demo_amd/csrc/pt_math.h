@@ -265,9 +265,12 @@ PT_HD f3 environment_term_rtg(f3 f0, float nov, float roughness)
 PT_HD f3 environment_color(float er, float eg, float eb, float ea, f3 d)
 {
     if (ea >= 0.0f) return make_f3(er, eg, eb);
-    float t = (d.y + 1.0f) * 0.5f;
-    float r = pt_fma(t, 0.5f - 1.0f, 1.0f), g = pt_fma(t, 0.7f - 1.0f, 1.0f);
-    return make_f3(from_srgb(r), from_srgb(g), 1.0f);  // blue: lerp(1,1,t) = 1 and FromSrgb(1) = 1 exactly
+    // Procedural sky FromSrgb(lerp(1, (0.5, 0.7, 1), (d.y + 1) / 2)): degree-7 polynomial fits in s = d.y of the exact
+    // per-channel function (DESIGN.md spec S5); blue is exactly 1.
+    float s = d.y;
+    float r = pt_fma(pt_fma(pt_fma(pt_fma(pt_fma(pt_fma(pt_fma(-3.77875438e-07f, s, -2.31609647e-06f), s, -1.62075557e-05f), s, -0.000163228658f), s, -0.00350578595f), s, 0.0846645609f), s, -0.389457047f), s, 0.522521555f);
+    float g = pt_fma(pt_fma(pt_fma(pt_fma(pt_fma(pt_fma(pt_fma(-5.82704285e-09f, s, -6.79562859e-08f), s, -9.30696501e-07f), s, -1.75486421e-05f), s, -0.000705873303f), s, 0.0319407657f), s, -0.275298983f), s, 0.69207108f);
+    return make_f3(r, g, 1.0f);
 }
 
 // ---------------------------------------------------------------- ray-sphere (replaces CastRay's triangle hit, RaytracingHelpers.hlsli:57-133)

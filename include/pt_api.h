@@ -46,7 +46,7 @@ typedef enum PtStatus {
 
 typedef struct PtConfig {
     int32_t device;         /* HIP device ordinal */
-    uint32_t tile_size;     /* multi-GPU tile edge in pixels; 0 -> 32 */
+    uint32_t tile_size;     /* multi-GPU tile edge in pixels, a power of two in [8, 1024]; 0 -> 32 */
     uint64_t stream;        /* hipStream_t to run on (e.g. a torch.cuda.Stream's handle); 0 -> context-owned stream, or the
                                legacy default (null) stream with PT_FLAG_DEFAULT_STREAM */
     uint32_t flags;         /* PT_FLAG_* */

@@ -311,11 +311,14 @@ static v3 environment_color(const PtSceneData *sd, v3 d)
 {
     if (sd->EnvironmentLightColor[3] >= 0.0f)
         return V3(sd->EnvironmentLightColor[0], sd->EnvironmentLightColor[1], sd->EnvironmentLightColor[2]);
-    float t = (d.y + 1.0f) * 0.5f;
-    /* lerp(1, (0.5,0.7,1), t) = 1 + t*(b-1) */
-    float r = FMA(t, 0.5f - 1.0f, 1.0f), g = FMA(t, 0.7f - 1.0f, 1.0f);
-    /* blue: lerp(1, 1, t) = fma(t, 0, 1) = 1 and FromSrgb(1) = 1 exactly (tests/test_oracle_kat.py) */
-    return V3(oracle_from_srgb(r), oracle_from_srgb(g), 1.0f);
+    /* Procedural sky: FromSrgb(lerp(1, (0.5, 0.7, 1), (d.y + 1) / 2)) per channel (ShadingHelpers.hlsli:29).  Each channel
+     * is a smooth function of s = d.y on [-1, 1]; it is evaluated as the degree-7 polynomial fit of that exact function
+     * (Chebyshev fit, |error| < 1e-9 in exact arithmetic, ~6e-8 in fp32 Horner) instead of three pow() calls.  Blue is
+     * lerp(1, 1, t) = 1 and FromSrgb(1) = 1 exactly.  DESIGN.md "Frozen arithmetic spec" S5. */
+    float s = d.y;
+    float r = FMA(FMA(FMA(FMA(FMA(FMA(FMA(-3.77875438e-07f, s, -2.31609647e-06f), s, -1.62075557e-05f), s, -0.000163228658f), s, -0.00350578595f), s, 0.0846645609f), s, -0.389457047f), s, 0.522521555f);
+    float g = FMA(FMA(FMA(FMA(FMA(FMA(FMA(-5.82704285e-09f, s, -6.79562859e-08f), s, -9.30696501e-07f), s, -1.75486421e-05f), s, -0.000705873303f), s, 0.0319407657f), s, -0.275298983f), s, 0.69207108f);
+    return V3(r, g, 1.0f);
 }
 void oracle_sky(const PtSceneData *scene, const float dir[3], float out[3])
 {

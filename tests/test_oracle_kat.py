@@ -69,6 +69,21 @@ def test_sincos_pow_accuracy(oracle):
         assert abs(lib.oracle_from_srgb(f32(cc)) - exp) < 2e-6
 
 
+def test_sky_polynomial_matches_exact_formula(oracle, dxrs, host):
+    """Spec S5: the procedural sky is a degree-7 polynomial fit of FromSrgb(lerp(1, (0.5, 0.7, 1), (d.y + 1) / 2))."""
+    lib = oracle.lib
+    sd = host.scene(dxrs.host.SCENE_SMALL)[2]
+    out = np.zeros(3, np.float32)
+    for y in np.linspace(-1, 1, 2001):
+        d = np.float32([math.sqrt(max(0.0, 1 - y * y)), y, 0])
+        lib.oracle_sky(C.addressof(sd), fptr(d), fptr(out))
+        t = (float(d[1]) + 1) / 2
+        for ch, c in enumerate((0.5, 0.7, 1.0)):
+            v = 1 + t * (c - 1)
+            assert abs(out[ch] - ((v + 0.055) / 1.055) ** 2.4) < 1.5e-7
+    assert out[2] == 1.0
+
+
 def test_get_basis(oracle):
     lib = oracle.lib
     t, b = np.zeros(3, np.float32), np.zeros(3, np.float32)
