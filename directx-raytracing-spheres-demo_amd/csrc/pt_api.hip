@@ -330,7 +330,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     const uint32_t tail_cap = c->num_cus * env_u32("PT_TAIL_BLOCKS_PER_CU", 8);
     auto grid_for = [](uint32_t items, uint32_t threads, uint32_t cap) { return std::max(1u, std::min((items + threads - 1) / threads, cap)); };
     const uint32_t trav_threads = traverse_threads(c->lds_scene);
-    const uint32_t fused_threads = c->lds_scene ? env_u32("PT_FUSED_THREADS", 256) : 256u;
+    const uint32_t fused_threads = c->lds_scene ? env_u32("PT_FUSED_THREADS", 512) : 256u;
     const uint32_t loop_threads = 256u;
     const size_t tail_after = env_u32("PT_TAIL_AFTER", split ? 3 : 1);     // wavefront bounces before the looping kernel (spp == 1)
     const uint32_t tail_threshold = env_u32("PT_TAIL_THRESHOLD", 262144);  // queue size below which spp > 1 switches to it

@@ -464,7 +464,9 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(SceneView sv, PixelM
 // per ray and no hit stream.  kLoop = true: the lane keeps alternating trace and shade_step until its pixel is done
 // (the persistent "tail" form for small queues).
 template <bool kLds, typename StackT, bool kPrimary, bool kLoop>
-__global__ __launch_bounds__(kFusedThreads) void bounce_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue qin, RayQueue qout,
+// 4 waves/SIMD (<= 128 VGPRs): two 512-thread workgroups per CU with the BVH in LDS (the unconstrained build takes 134
+// VGPRs for the primary variant and drops to 3 waves/SIMD: measured 171 -> 149 us for the two compacting passes at C2)
+__global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void bounce_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue qin, RayQueue qout,
                                                                Scratch scratch, float4* __restrict__ out,
                                                                const uint32_t* __restrict__ count_in_ptr, uint32_t* __restrict__ count_out_ptr,
                                                                FrameCounters fc)
