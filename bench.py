@@ -126,6 +126,25 @@ def main():
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     tot = r.totals(reset=True)
+    queue_sizes = r.queue_sizes() if args.spp == 1 else []
+    # Second timed region, identical except that a HIP event pair brackets every kernel launch on the stream it runs on:
+    # it provides the per-launch durations of the roofline object.  (The event records cost ~10 % of frame time at this
+    # frame size, which is why `value` comes from the first region.)
+    prof, elapsed_ev = None, None
+    if not args.no_roofline:
+        r.set_profiling(True)
+        sync_all()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            step(args.warmup + args.steps + k)
+        torch.cuda.synchronize(dev)
+        if tiled:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        elapsed_ev = time.perf_counter() - t1
+        prof = r.profile(reset=True)
+        r.set_profiling(False)
+        tot_ev = r.totals(reset=True)
     rays, paths = int(tot.rays), int(tot.paths)
     if tiled:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -162,51 +181,48 @@ def main():
             },
         }
 
-    # ---- roofline of the dominant kernel: per-launch HIP events on the render stream (rank 0's own tiles when N > 1)
-    if not args.no_roofline:
-        r.set_profiling(True)
-        n_prof = max(1, min(args.steps, 20))
-        agg = {"ms_trav": 0.0, "ms_shade": 0.0, "ms_tail": 0.0, "n_trav": 0, "n_shade": 0, "n_tail": 0, "rays": 0, "slots": 0, "pixels": 0}
-        for k in range(n_prof):
-            gs.FrameIndex = args.warmup + k
-            r.set_camera(cams[(args.warmup + k) % 8])
-            r.set_constants(gs)
-            st = r.render_device(frame.data_ptr(), want_stats=True) if not tiled else r.render_tiles(packed.data_ptr(), want_stats=True)
-            agg["ms_trav"] += st.ms_traverse
-            agg["ms_shade"] += st.ms_shade
-            agg["n_trav"] += st.traverse_launches
-            agg["n_shade"] += st.shade_launches
-            agg["ms_tail"] += st.ms_tail
-            agg["n_tail"] += st.tail_launches
-            agg["rays"] += int(st.rays)
-            agg["pixels"] += int(st.pixels)
-        r.set_profiling(False)
-        if rank == 0:
-            # DESIGN.md byte model for the fused schedule: a compacting bounce pass reads 48 B per ray of its input queue
-            # (none for the primary pass, which generates its rays), writes 48 B per ray it emits and 16 B per pixel it
-            # finishes; the looping pass reads 48 B per queued ray and writes 16 B per pixel it finishes.
-            qs = r.queue_sizes() if args.spp == 1 else []
-            secondary = agg["rays"] - agg["pixels"]
-            n_wf = agg["n_trav"] // n_prof  # compacting passes per frame (incl. the primary pass)
-            if qs and len(qs) > n_wf:
-                wf_in = sum(qs[1:n_wf]); wf_out = sum(qs[1:n_wf + 1]); loop_in = qs[n_wf]
-            else:  # no per-queue sizes (spp > 1): every secondary ray is written once and read once
-                wf_in = wf_out = secondary / n_prof; loop_in = 0
-            px = agg["pixels"] / n_prof
-            bytes_wf = (48 * wf_in + 48 * wf_out + 16 * px) * n_prof
-            bytes_loop = (48 * loop_in + 16 * loop_in) * n_prof
-            if agg["ms_trav"] >= agg["ms_tail"]:
-                name, b, ms, n = "bounce_kernel (compacting trace+shade passes)", bytes_wf, agg["ms_trav"], agg["n_trav"]
-            else:
-                name, b, ms, n = "bounce_kernel<loop> (looping trace+shade pass)", bytes_loop, agg["ms_tail"], agg["n_tail"]
-            achieved = (b / n) / (ms / n * 1e-3) / 1e9 if n and ms > 0 else 0.0
-            result["roofline"] = {
-                "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "bytes_per_launch": b / max(n, 1), "avg_launch_ms": ms / max(n, 1), "launches_per_frame": n / n_prof,
-                "traverse_ms_per_frame": agg["ms_trav"] / n_prof, "shade_ms_per_frame": agg["ms_shade"] / n_prof,
-                "tail_ms_per_frame": agg["ms_tail"] / n_prof,
-            }
+    # ---- roofline of the dominant kernel class, from the per-launch HIP events of the timed region itself (this rank)
+    if not args.no_roofline and rank == 0:
+        n_f = args.steps
+        my_pixels = tot_ev.pixels / n_f
+        my_secondary = (tot_ev.rays - tot_ev.pixels) / n_f
+        n_wf = prof.traverse_launches // n_f  # compacting passes per frame (incl. the primary pass)
+        # DESIGN.md byte model (fused schedule): a compacting pass reads 48 B per ray of its input queue (none for the
+        # primary pass, which generates its rays), writes 48 B per ray it emits and 16 B per pixel it finishes; the
+        # looping pass reads 48 B per queued ray and writes 16 B per pixel it finishes.
+        qs = queue_sizes
+        if qs and len(qs) > n_wf >= 1:
+            wf_in, wf_out, loop_in = sum(qs[1:n_wf]), sum(qs[1:n_wf + 1]), qs[n_wf]
+            px_wf = qs[0] - loop_in if world == 1 else my_pixels - loop_in
+        else:  # no per-queue sizes (spp > 1): every secondary ray is written once and read once
+            wf_in = wf_out = my_secondary; loop_in = 0; px_wf = my_pixels
+        bytes_wf = (48 * wf_in + 48 * wf_out + 16 * px_wf) * n_f
+        bytes_loop = (48 * loop_in + 16 * loop_in) * n_f
+        split = prof.shade_launches > 0
+        if split:  # split schedule (BVH in global memory): traverse-type launches read o,d and write hits; see DESIGN.md
+            name, b, ms, n = "traverse_kernel (+ primary_kernel)", (40 * my_secondary + 56 * qs[0] if qs else 40 * my_secondary) * n_f, prof.ms_traverse, prof.traverse_launches
+        elif prof.ms_traverse >= prof.ms_tail:
+            name, b, ms, n = "bounce_kernel (compacting trace+shade passes)", bytes_wf, prof.ms_traverse, prof.traverse_launches
+        else:
+            name, b, ms, n = "bounce_kernel<loop> (looping trace+shade pass)", bytes_loop, prof.ms_tail, prof.tail_launches
+        achieved = (b / n) / (ms / n * 1e-3) / 1e9 if n and ms > 0 else 0.0
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the guide prescribes)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pmc.get("workload") == f"{args.scene}-{w}x{h}-{args.spp}spp-{args.bounces}b" and not split:
+                key = "bounce<loop>" if "loop" in name else "bounce<wavefront>"
+                traffic = pmc[key]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+        result["roofline"] = {
+            "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "bytes_per_launch": b / max(n, 1), "avg_launch_ms": ms / max(n, 1), "launches_per_frame": n / n_f,
+            "compacting_ms_per_frame": prof.ms_traverse / n_f, "shade_ms_per_frame": prof.ms_shade / n_f, "loop_ms_per_frame": prof.ms_tail / n_f,
+            "ms_per_step_with_events": elapsed_ev / n_f * 1e3,
+            "note": "per-launch HIP events over a second timed region of the same K steps; with two frames in flight launches of "
+                    "consecutive frames overlap, so per-launch durations add up to more than ms_per_step",
+        }
 
     # ---- CPU baseline: the scalar oracle on this node's host cores, bounded sample of the same frame (rank 0, N = 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

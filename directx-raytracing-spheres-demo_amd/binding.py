@@ -17,7 +17,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR
 API_SYMBOLS = [
     "pt_create", "pt_destroy", "pt_set_scene", "pt_build_accel", "pt_set_camera", "pt_set_constants", "pt_render",
     "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_trace_rays", "pt_accel_download",
-    "pt_accel_download_order", "pt_lbvh_build_host", "pt_set_profiling", "pt_get_totals", "pt_get_queue_sizes", "pt_synchronize", "pt_last_error", "pt_version",
+    "pt_accel_download_order", "pt_lbvh_build_host", "pt_set_profiling", "pt_get_profile", "pt_get_totals", "pt_get_queue_sizes", "pt_synchronize", "pt_last_error", "pt_version",
 ]
 
 
@@ -70,6 +70,8 @@ class HipLib:
         lib.pt_lbvh_build_host.argtypes = [vp, u32, vp, vp, C.POINTER(u32)]
         lib.pt_set_profiling.restype = C.c_int
         lib.pt_set_profiling.argtypes = [vp, C.c_int]
+        lib.pt_get_profile.restype = C.c_int
+        lib.pt_get_profile.argtypes = [vp, C.POINTER(PtStats), C.c_int]
         lib.pt_get_totals.restype = C.c_int
         lib.pt_get_totals.argtypes = [vp, C.POINTER(PtStats), C.c_int]
         lib.pt_get_queue_sizes.restype = C.c_int
@@ -173,6 +175,12 @@ class Renderer:
 
     def set_profiling(self, enabled):
         self._check(self._lib.pt_set_profiling(self._ctx, 1 if enabled else 0))
+
+    def profile(self, reset=False):
+        """Summed per-launch event times over every render call since profiling was switched on (synchronises)."""
+        stats = PtStats()
+        self._check(self._lib.pt_get_profile(self._ctx, C.byref(stats), 1 if reset else 0))
+        return stats
 
     def totals(self, reset=False):
         """Device-accumulated totals over all render calls since the last reset (synchronises)."""

@@ -223,6 +223,7 @@ uint32_t env_u32(const char* name, uint32_t dflt)
 
 EventPair* next_events(PtContext* c, int kind)
 {
+    if (c->ev_used >= (1u << 20)) return nullptr;  // bounded pool: profiling left on for a long run simply stops recording
     if (c->ev_used == c->ev_pool.size()) {
         EventPair p{};
         if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
@@ -267,6 +268,19 @@ hipError_t flush_all_counters(Lane& L)
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+void sum_events(PtContext* c, size_t begin, size_t end, PtStats* stats)
+{
+    for (size_t i = begin; i < end; i++) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, c->ev_pool[i].a, c->ev_pool[i].b) != hipSuccess) continue;
+        switch (c->ev_pool[i].kind) {
+            case 2: stats->ms_shade += t; stats->shade_launches++; break;
+            case 3: stats->ms_tail += t; stats->tail_launches++; break;
+            default: stats->ms_traverse += t; stats->traverse_launches++; break;  // primary / fused bounce / traverse
+        }
+    }
 }
 
 // The per-frame launch sequence.  out: device float4 buffer addressed by PixelRef::out_index.
@@ -336,7 +350,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     const uint32_t tail_threshold = env_u32("PT_TAIL_THRESHOLD", 262144);  // queue size below which spp > 1 switches to it
 
     const bool timed = stats != nullptr;
-    c->ev_used = 0;
+    const size_t ev_begin = c->ev_used;  // this frame's slice of the per-launch event pool
     if (timed) PT_HIP(c, hipEventRecord(c->ev0, L.stream));
 
     auto bracket = [&](int kind, auto&& launch) -> hipError_t {
@@ -448,17 +462,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         stats->pixels = valid_pixels;
         stats->paths = valid_pixels * spp;
         stats->bytes_algorithmic = bytes_per_secondary(split) * secondary + fixed_bytes(split, pm.n_slots, valid_pixels, spp > 1 ? valid_pixels * spp : 0);
-        if (c->profiling) {
-            for (size_t i = 0; i < c->ev_used; i++) {
-                float t = 0;
-                if (hipEventElapsedTime(&t, c->ev_pool[i].a, c->ev_pool[i].b) != hipSuccess) continue;
-                switch (c->ev_pool[i].kind) {
-                    case 2: stats->ms_shade += t; stats->shade_launches++; break;
-                    case 3: stats->ms_tail += t; stats->tail_launches++; break;
-                    default: stats->ms_traverse += t; stats->traverse_launches++; break;  // primary / fused bounce / traverse
-                }
-            }
-        }
+        if (c->profiling) sum_events(c, ev_begin, c->ev_used, stats);
     }
     return PT_OK;
 }
@@ -811,7 +815,21 @@ PtStatus pt_accel_download_order(PtContext* c, uint32_t* sorted_id, uint32_t cap
 PtStatus pt_set_profiling(PtContext* c, int enabled)
 {
     if (!c) return PT_ERR_INVALID_ARG;
+    PT_HIP(c, sync_all(c));
     c->profiling = enabled != 0;
+    c->ev_used = 0;
+    return PT_OK;
+}
+
+PtStatus pt_get_profile(PtContext* c, PtStats* profile, int reset)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!profile) return fail(c, PT_ERR_INVALID_ARG, "pt_get_profile: null output");
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, sync_all(c));
+    std::memset(profile, 0, sizeof *profile);
+    sum_events(c, 0, c->ev_used, profile);
+    if (reset) c->ev_used = 0;
     return PT_OK;
 }
 

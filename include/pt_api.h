@@ -142,8 +142,12 @@ PtStatus pt_accel_download_order(PtContext *ctx, uint32_t *sorted_id, uint32_t c
 /* Host LBVH builder (the PT_FLAG_HOST_LBVH path), callable without a context or a GPU, for structural tests:
  * nodes[n-1], sorted_id[n]; returns the tree depth through *depth. */
 PtStatus pt_lbvh_build_host(const PtSphere *spheres, uint32_t n, PtBvhNode *nodes, uint32_t *sorted_id, uint32_t *depth);
-/* Turn per-kernel hipEvent profiling on/off (adds event records around every launch; disables the graph). */
+/* Turn per-launch hipEvent profiling on/off (an event pair around every kernel launch, on the stream it runs on). */
 PtStatus pt_set_profiling(PtContext *ctx, int enabled);
+/* Sum of the per-launch event times recorded since profiling was switched on / last reset, over every render call
+ * (synchronises): ms_traverse / traverse_launches = compacting passes (and split-schedule primary / traverse launches),
+ * ms_shade / shade_launches = split-schedule shade launches, ms_tail / tail_launches = looping passes. */
+PtStatus pt_get_profile(PtContext *ctx, PtStats *profile, int reset);
 /* Running totals over every render call since the last reset, accumulated on the device without host
  * synchronisation (rays, paths, pixels, bytes_algorithmic; the timing fields are zero).  Synchronises the stream. */
 PtStatus pt_get_totals(PtContext *ctx, PtStats *totals, int reset);
