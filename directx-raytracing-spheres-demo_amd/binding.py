@@ -16,7 +16,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR
 # every symbol include/pt_api.h declares
 API_SYMBOLS = [
     "pt_create", "pt_destroy", "pt_set_scene", "pt_build_accel", "pt_set_camera", "pt_set_constants", "pt_render",
-    "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_trace_rays", "pt_accel_download",
+    "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_trace_rays", "pt_trace_rays_stats", "pt_accel_download",
     "pt_accel_download_order", "pt_lbvh_build_host", "pt_set_profiling", "pt_get_profile", "pt_get_totals", "pt_get_queue_sizes", "pt_synchronize", "pt_last_error", "pt_version",
 ]
 
@@ -62,6 +62,8 @@ class HipLib:
         lib.pt_unpack_tiles.argtypes = [vp, vp, u32, vp]
         lib.pt_trace_rays.restype = C.c_int
         lib.pt_trace_rays.argtypes = [vp, vp, vp, u32, C.c_float, C.c_int, vp, vp]
+        lib.pt_trace_rays_stats.restype = C.c_int
+        lib.pt_trace_rays_stats.argtypes = [vp, vp, vp, u32, C.c_float, vp, vp, vp]
         lib.pt_accel_download.restype = C.c_int
         lib.pt_accel_download.argtypes = [vp, vp, u32]
         lib.pt_accel_download_order.restype = C.c_int
@@ -231,6 +233,17 @@ class Renderer:
         ids = np.empty(n, dtype=np.uint32)
         self._check(self._lib.pt_trace_rays(self._ctx, o.ctypes.data, d.ctypes.data, n, tmin, 1 if use_bvh else 0, t.ctypes.data, ids.ctypes.data))
         return t, ids
+
+    def trace_rays_stats(self, origins, directions, tmin=0.0):
+        """-> (t, ids, visits) with visits[:, 0] = internal nodes visited, visits[:, 1] = spheres tested per ray"""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        n = len(o)
+        t = np.empty(n, dtype=np.float32)
+        ids = np.empty(n, dtype=np.uint32)
+        visits = np.zeros((n, 2), dtype=np.uint32)
+        self._check(self._lib.pt_trace_rays_stats(self._ctx, o.ctypes.data, d.ctypes.data, n, tmin, t.ctypes.data, ids.ctypes.data, visits.ctypes.data))
+        return t, ids, visits
 
     def download_accel(self):
         n = self.accel.node_count

@@ -759,7 +759,8 @@ PtStatus pt_unpack_tiles(PtContext* c, const void* gathered, uint32_t max_tiles_
     return PT_OK;
 }
 
-PtStatus pt_trace_rays(PtContext* c, const float* origins, const float* directions, uint32_t n, float tmin, int use_bvh, float* out_t, uint32_t* out_id)
+static PtStatus trace_rays_impl(PtContext* c, const float* origins, const float* directions, uint32_t n, float tmin, int use_bvh, float* out_t,
+                                uint32_t* out_id, uint32_t* out_visits)
 {
     if (!c) return PT_ERR_INVALID_ARG;
     if (!origins || !directions || !out_t || !out_id) return fail(c, PT_ERR_INVALID_ARG, "pt_trace_rays: null pointer");
@@ -768,25 +769,40 @@ PtStatus pt_trace_rays(PtContext* c, const float* origins, const float* directio
     PT_HIP(c, hipSetDevice(c->device));
     float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
     uint32_t* d_id = nullptr;
+    uint2* d_v = nullptr;
     PtStatus st = PT_OK;
-    auto cleanup = [&] { free_dev(d_o); free_dev(d_d); free_dev(d_t); free_dev(d_id); };
+    auto cleanup = [&] { free_dev(d_o); free_dev(d_d); free_dev(d_t); free_dev(d_id); free_dev(d_v); };
     hipError_t e;
     if ((e = hipMalloc(&d_o, (size_t)n * 12)) != hipSuccess || (e = hipMalloc(&d_d, (size_t)n * 12)) != hipSuccess
-        || (e = hipMalloc(&d_t, (size_t)n * 4)) != hipSuccess || (e = hipMalloc(&d_id, (size_t)n * 4)) != hipSuccess) {
+        || (e = hipMalloc(&d_t, (size_t)n * 4)) != hipSuccess || (e = hipMalloc(&d_id, (size_t)n * 4)) != hipSuccess
+        || (out_visits && use_bvh && (e = hipMalloc(&d_v, (size_t)n * 8)) != hipSuccess)) {
         cleanup();
         return fail(c, PT_ERR_OOM, std::string("pt_trace_rays: ") + hipGetErrorString(e));
     }
     const SceneView sv = make_scene_view(c);
     if ((e = hipMemcpyAsync(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice, c->stream)) != hipSuccess
         || (e = hipMemcpyAsync(d_d, directions, (size_t)n * 12, hipMemcpyHostToDevice, c->stream)) != hipSuccess
-        || (e = launch_trace(sv, d_o, d_d, n, tmin, use_bvh, d_t, d_id, c->stream)) != hipSuccess
+        || (e = launch_trace(sv, d_o, d_d, n, tmin, use_bvh, d_t, d_id, d_v, c->stream)) != hipSuccess
         || (e = hipMemcpyAsync(out_t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess
         || (e = hipMemcpyAsync(out_id, d_id, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess
+        || (d_v && (e = hipMemcpyAsync(out_visits, d_v, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream)) != hipSuccess)
         || (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
         st = fail(c, PT_ERR_HIP, std::string("pt_trace_rays: ") + hipGetErrorString(e));
     }
     cleanup();
     return st;
+}
+
+PtStatus pt_trace_rays(PtContext* c, const float* origins, const float* directions, uint32_t n, float tmin, int use_bvh, float* out_t, uint32_t* out_id)
+{
+    return trace_rays_impl(c, origins, directions, n, tmin, use_bvh, out_t, out_id, nullptr);
+}
+
+PtStatus pt_trace_rays_stats(PtContext* c, const float* origins, const float* directions, uint32_t n, float tmin, float* out_t, uint32_t* out_id,
+                             uint32_t* out_visits)
+{
+    if (c && !out_visits) return fail(c, PT_ERR_INVALID_ARG, "pt_trace_rays_stats: null pointer");
+    return trace_rays_impl(c, origins, directions, n, tmin, 1, out_t, out_id, out_visits);
 }
 
 PtStatus pt_accel_download(PtContext* c, PtBvhNode* nodes, uint32_t capacity)

@@ -22,7 +22,7 @@ hipError_t launch_traverse(const SceneView& sv, const RayQueue& q, const uint32_
 hipError_t launch_shade(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const RayQueue& qout,
                         const Scratch& scratch, float4* out, const uint32_t* count_in, uint32_t* count_out, uint32_t grid, hipStream_t stream);
 hipError_t launch_trace(const SceneView& sv, const float* o, const float* d, uint32_t n_rays, float tmin, int use_bvh, float* out_t,
-                        uint32_t* out_id, hipStream_t stream);
+                        uint32_t* out_id, uint2* out_visits, hipStream_t stream);
 hipError_t launch_tail(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const Scratch& scratch, float4* out,
                        const uint32_t* count_ptr, unsigned long long* tail_rays, uint32_t grid, hipStream_t stream);
 hipError_t launch_flush_counters(uint32_t* counts, uint32_t n_counts, unsigned long long* tail, unsigned long long* totals, hipStream_t stream);

@@ -80,11 +80,12 @@ constexpr int kTraversalDone = (int)0x80000000;  // not a valid leaf code (leaf 
 // address space is inferred after inlining).  stack: per-lane stack, entry e of lane l at stack[e * stride + l].
 // The result is identical to brute force: nearest t, ties -> lowest original id (leaf boxes are padded so the slab
 // test is conservative w.r.t. intersect_sphere; culling is <=).
-template <typename StackT>
+template <typename StackT, bool kCount = false>
 __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, const float4* __restrict__ sph,
                                             const uint32_t* __restrict__ ids, uint32_t n, f3 o, f3 d, float tmin, float tmax,
-                                            StackT* stack, uint32_t stride, float& t_out, uint32_t& id_out)
+                                            StackT* stack, uint32_t stride, float& t_out, uint32_t& id_out, uint32_t* visits = nullptr)
 {
+    uint32_t n_nodes_visited = 0, n_spheres_tested = 0;  // kCount only (pt_trace_rays statistics hook)
     float best = tmax;
     uint32_t best_id = kMissId;
     if (n == 1) {
@@ -100,6 +101,7 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
     uint32_t sp = 0;
     for (;;) {
         while (node >= 0) {
+            if (kCount) n_nodes_visited++;
             const float4 n0 = nodes[node * 4 + 0];
             const float4 n1 = nodes[node * 4 + 1];
             const float4 n2 = nodes[node * 4 + 2];
@@ -136,6 +138,7 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
         }
         if (node == kTraversalDone) break;
         {
+            if (kCount) n_spheres_tested++;
             const uint32_t k = ~(uint32_t)node;
             const float4 s = sph[k];
             float t;
@@ -150,6 +153,7 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
     }
     // t < tmax is required by intersect_sphere's contract: best starts at tmax and only shrinks
     t_out = best; id_out = best_id;
+    if (kCount && visits) { visits[0] = n_nodes_visited; visits[1] = n_spheres_tested; }
 }
 
 // ------------------------------------------------------------------------------------------------ primary
@@ -559,7 +563,8 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
 // ------------------------------------------------------------------------------------------------ test hooks
 template <bool kLds, typename StackT>
 __global__ __launch_bounds__(kTraverseThreads) void trace_kernel(SceneView sv, const float* __restrict__ o, const float* __restrict__ d,
-                                                                 uint32_t n_rays, float tmin, float* __restrict__ out_t, uint32_t* __restrict__ out_id)
+                                                                 uint32_t n_rays, float tmin, float* __restrict__ out_t, uint32_t* __restrict__ out_id,
+                                                                 uint2* __restrict__ out_visits)
 {
     extern __shared__ float4 smem[];
     const float4* nodes = sv.nodes;
@@ -579,10 +584,16 @@ __global__ __launch_bounds__(kTraverseThreads) void trace_kernel(SceneView sv, c
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rays; i += gridDim.x * blockDim.x) {
         float t;
         uint32_t id;
-        closest_hit<StackT>(nodes, sph, ids, sv.n, make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
-                            tmin, kInf, stack, blockDim.x, t, id);
+        uint32_t v[2] = { 0, 0 };
+        if (out_visits)
+            closest_hit<StackT, true>(nodes, sph, ids, sv.n, make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
+                                      tmin, kInf, stack, blockDim.x, t, id, v);
+        else
+            closest_hit<StackT>(nodes, sph, ids, sv.n, make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
+                                tmin, kInf, stack, blockDim.x, t, id);
         out_t[i] = t;
         out_id[i] = id;
+        if (out_visits) out_visits[i] = make_uint2(v[0], v[1]);
     }
 }
 
@@ -717,13 +728,13 @@ hipError_t launch_shade(const SceneView& sv, const PixelMap& pm, const FramePara
 }
 
 hipError_t launch_trace(const SceneView& sv, const float* o, const float* d, uint32_t n_rays, float tmin, int use_bvh, float* out_t,
-                        uint32_t* out_id, hipStream_t stream)
+                        uint32_t* out_id, uint2* out_visits, hipStream_t stream)
 {
     const uint32_t tt = traverse_threads(sv.lds_scene != 0);
     const uint32_t grid = (n_rays + tt - 1) / tt < 2048u ? (n_rays + tt - 1) / tt : 2048u;
     if (grid == 0) return hipSuccess;
     if (use_bvh) {
-        PT_DISPATCH_TRAVERSE(trace_kernel, grid, stream, sv, o, d, n_rays, tmin, out_t, out_id);
+        PT_DISPATCH_TRAVERSE(trace_kernel, grid, stream, sv, o, d, n_rays, tmin, out_t, out_id, out_visits);
     } else {
         hipLaunchKernelGGL(brute_kernel, dim3(grid), dim3(kTraverseThreads), 0, stream, sv, o, d, n_rays, tmin, out_t, out_id);
     }

@@ -279,13 +279,17 @@ PT_HD bool intersect_sphere(f3 o, f3 d, float tmin, float tmax, f3 C, float r, f
 {
     f3 f = o - C;
     float bp = -dot(f, d);
-    f3 l = mad(bp, d, f);
     float r2 = r * r;
+    float cc = dot(f, f) - r2;
+    // Early out (changes no result for tmin >= 0): origin outside the sphere and the closest approach behind it ->
+    // q = bp - sqrt(disc) < 0 and cc / q < 0, i.e. both roots are negative and the spec'd test t > tmin fails anyway.
+    // It skips the sqrt + division for every sphere a ray is leaving (the ground sphere, for every bounce ray).
+    if (cc > 0.0f && bp < 0.0f) return false;
+    f3 l = mad(bp, d, f);
     float disc = r2 - dot(l, l);
     if (!(disc >= 0.0f)) return false;
     float sq = pt_sqrt(disc);
     float q = bp + (bp >= 0.0f ? sq : -sq);
-    float cc = dot(f, f) - r2;
     float ta = cc / q;
     float tb = q;
     float t0 = ta < tb ? ta : tb;

@@ -135,6 +135,10 @@ PtStatus pt_unpack_tiles(PtContext *ctx, const void *gathered_device, uint32_t m
  * Outputs host arrays t[n], id[n] (id = 0xFFFFFFFF on miss).  use_bvh = 0 runs the device brute-force kernel. */
 PtStatus pt_trace_rays(PtContext *ctx, const float *origins, const float *directions, uint32_t n, float tmin,
                        int use_bvh, float *out_t, uint32_t *out_id);
+/* As pt_trace_rays through the LBVH, additionally returning per ray {internal nodes visited, spheres tested}
+ * (out_visits: n * 2 uint32). */
+PtStatus pt_trace_rays_stats(PtContext *ctx, const float *origins, const float *directions, uint32_t n, float tmin,
+                             float *out_t, uint32_t *out_id, uint32_t *out_visits);
 /* Copy the device BVH to host: nodes[node_count]; leaf child c < 0 refers to Morton-sorted index ~c, whose
  * original sphere id is sorted_id[~c] (pt_accel_download_order: sorted_id[leaf_count]). */
 PtStatus pt_accel_download(PtContext *ctx, PtBvhNode *nodes, uint32_t capacity);
