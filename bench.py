@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--spheres", type=int, default=1 << 20, help="sphere count of the procedural scene")
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
                     help="2: consecutive frames alternate between two streams / output buffers so one frame's tail overlaps the next frame's start")
+    ap.add_argument("--animate", action="store_true",
+                    help="demo scene in motion (closed-form springs + Moon orbit, 1/60 s per frame): per-frame sphere upload + LBVH refit inside the timed region")
     ap.add_argument("--force-tiles", action="store_true", help="run the tile / gather / un-swizzle path even with one rank (rehearsal of the N > 1 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -94,9 +96,16 @@ def main():
             frame = torch.empty((h * w, 4), dtype=torch.float32, device=dev)
 
     cams = [host.camera(w, h, jitter_index=k, jitter_count=8) for k in range(8)]
+    if args.animate:
+        if args.scene != "demo":
+            raise SystemExit("--animate is defined for the demo scene")
+        n_anim = 2 * args.steps + args.warmup + 8
+        anim = [host.scene_at_time(0, k / 60.0) for k in range(n_anim)]  # host-side Tick (MyScene::SetTime), precomputed
 
     def step(k):
         gs.FrameIndex = k
+        if args.animate:
+            r.update_spheres(anim[k])  # upload + LBVH refit on this frame's stream (Scene::Refresh + TLAS rebuild analogue)
         r.set_camera(cams[k % 8])
         r.set_constants(gs)
         if not tiled:
@@ -176,6 +185,7 @@ def main():
                 "workload": f"{args.scene} sphere scene (seed 0, {len(spheres)} spheres), {w}x{h}, {args.spp} spp, {args.bounces} bounces, RR on, sky env"
                             + (f", 32x32 tiles interleaved over {world} GPU(s) + RCCL gather to rank 0" if tiled else ""),
                 "frames_in_flight": args.frames_in_flight,
+                "animated": bool(args.animate),
                 "rays_per_frame": rays / args.steps,
                 "lbvh": {"nodes": int(accel.node_count), "depth": int(accel.depth), "lds_resident": bool(accel.lds_resident), "build_ms": float(accel.build_ms)},
             },

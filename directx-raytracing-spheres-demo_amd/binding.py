@@ -7,7 +7,7 @@ import os
 
 import numpy as np
 
-from .types import (BVH_NODE_DTYPE, PtAccelInfo, PtCamera, PtConfig, PtGraphicsSettings, PtRect, PtSceneData, PtStats)
+from .abi_types import (BVH_NODE_DTYPE, PtAccelInfo, PtCamera, PtConfig, PtGraphicsSettings, PtRect, PtSceneData, PtStats)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 
@@ -15,7 +15,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR
 
 # every symbol include/pt_api.h declares
 API_SYMBOLS = [
-    "pt_create", "pt_destroy", "pt_set_scene", "pt_build_accel", "pt_set_camera", "pt_set_constants", "pt_render",
+    "pt_create", "pt_destroy", "pt_set_scene", "pt_build_accel", "pt_update_spheres", "pt_refit_accel", "pt_set_camera", "pt_set_constants", "pt_render",
     "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_trace_rays", "pt_trace_rays_stats", "pt_accel_download",
     "pt_accel_download_order", "pt_lbvh_build_host", "pt_set_profiling", "pt_get_profile", "pt_get_totals", "pt_get_queue_sizes", "pt_synchronize", "pt_last_error", "pt_version",
 ]
@@ -46,6 +46,10 @@ class HipLib:
         lib.pt_set_scene.argtypes = [vp, vp, vp, u32, C.POINTER(PtSceneData)]
         lib.pt_build_accel.restype = C.c_int
         lib.pt_build_accel.argtypes = [vp, C.POINTER(PtAccelInfo)]
+        lib.pt_update_spheres.restype = C.c_int
+        lib.pt_update_spheres.argtypes = [vp, vp, u32]
+        lib.pt_refit_accel.restype = C.c_int
+        lib.pt_refit_accel.argtypes = [vp]
         lib.pt_set_camera.restype = C.c_int
         lib.pt_set_camera.argtypes = [vp, C.POINTER(PtCamera)]
         lib.pt_set_constants.restype = C.c_int
@@ -161,6 +165,14 @@ class Renderer:
         self._check(self._lib.pt_build_accel(self._ctx, C.byref(info)))
         self.accel = info
         return info
+
+    def update_spheres(self, spheres, refit=True):
+        """New centres / radii for the same objects, applied to the next frame (asynchronous); refit the LBVH boxes."""
+        spheres = np.ascontiguousarray(spheres)
+        assert spheres.dtype.itemsize == 16
+        self._check(self._lib.pt_update_spheres(self._ctx, spheres.ctypes.data, len(spheres)))
+        if refit:
+            self._check(self._lib.pt_refit_accel(self._ctx))
 
     def set_camera(self, camera):
         self._check(self._lib.pt_set_camera(self._ctx, C.byref(camera)))

@@ -49,6 +49,17 @@ struct Lane {
     uint32_t* h_prev_counts = nullptr;
     uint64_t prev_signature = 0;
     unsigned long long* d_totals = nullptr;  // [0] running secondary-ray total, [1] last folded frame, [2],[3] tail counters
+    // private copy of the moving part of the scene (pt_update_spheres / pt_refit_accel): spheres, Morton-ordered spheres
+    // and node boxes; null = this lane renders the context's master scene
+    float4* d_sph = nullptr;
+    float4* d_sph_sorted = nullptr;
+    float4* d_nodes = nullptr;
+    uint32_t* d_refit_flags = nullptr;
+    uint32_t* d_refit_hdr = nullptr;
+    PtSphere* h_stage = nullptr;      // pinned upload staging
+    hipEvent_t ev_upload = nullptr;   // the last upload from h_stage has been consumed
+    uint32_t scene_n = 0;             // sphere count the private copy was allocated for
+    bool scene_private = false;
 };
 constexpr uint32_t kMaxLanes = 2;
 
@@ -126,6 +137,14 @@ void free_dev(T*& p)
     if (p) { (void)hipFree(p); p = nullptr; }
 }
 
+void free_lane_scene(Lane& L)
+{
+    free_dev(L.d_sph); free_dev(L.d_sph_sorted); free_dev(L.d_nodes); free_dev(L.d_refit_flags); free_dev(L.d_refit_hdr);
+    if (L.h_stage) { (void)hipHostFree(L.h_stage); L.h_stage = nullptr; }
+    L.scene_n = 0;
+    L.scene_private = false;
+}
+
 void free_lane_buffers(Lane& L)
 {
     for (auto& q : L.q) { free_dev(q.q0); free_dev(q.q1); free_dev(q.q2); free_dev(q.hit); }
@@ -185,13 +204,14 @@ PtStatus validate_frame(PtContext* c)
     return PT_OK;
 }
 
-SceneView make_scene_view(const PtContext* c)
+SceneView make_scene_view(const PtContext* c, const Lane* L = nullptr)
 {
     SceneView sv{};
-    sv.nodes = c->d_nodes;
-    sv.sph_sorted = c->d_sph_sorted;
+    const bool priv = L && L->scene_private;
+    sv.nodes = priv ? L->d_nodes : c->d_nodes;
+    sv.sph_sorted = priv ? L->d_sph_sorted : c->d_sph_sorted;
     sv.sorted_id = c->d_sorted_id;
-    sv.sph = c->d_sph;
+    sv.sph = priv ? L->d_sph : c->d_sph;
     sv.mats = c->d_mats;
     sv.n = c->n;
     sv.n_nodes = c->n_nodes;
@@ -322,7 +342,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         c->calls++;
     }
 
-    const SceneView sv = make_scene_view(c);
+    const SceneView sv = make_scene_view(c, &L);
     const FrameParams fp = make_frame_params(c);
     L.parity ^= 1u;
     const FrameCounters fc = make_counters(L, L.parity);
@@ -530,6 +550,8 @@ void pt_destroy(PtContext* c)
     (void)sync_all(c);
     for (auto& L : c->lanes) {
         free_lane_buffers(L);
+        free_lane_scene(L);
+        if (L.ev_upload) (void)hipEventDestroy(L.ev_upload);
         free_dev(L.d_counts); free_dev(L.d_totals);
         if (L.h_counts) (void)hipHostFree(L.h_counts);
         if (L.h_prev_counts) (void)hipHostFree(L.h_prev_counts);
@@ -582,6 +604,7 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
     c->sd = *sd;
     c->scene_set = true;
     c->accel_valid = false;
+    for (auto& L : c->lanes) L.scene_private = false;  // every lane renders the new master scene
     return PT_OK;
 }
 
@@ -639,6 +662,55 @@ PtStatus pt_build_accel(PtContext* c, PtAccelInfo* info)
         for (int a = 0; a < 3; a++) { info->bounds_min[a] = c->lbvh.bounds_min[a]; info->bounds_max[a] = c->lbvh.bounds_max[a]; }
         info->build_ms = build_ms;
     }
+    return PT_OK;
+}
+
+PtStatus pt_update_spheres(PtContext* c, const PtSphere* spheres, uint32_t n)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!spheres) return fail(c, PT_ERR_INVALID_ARG, "pt_update_spheres: null pointer");
+    if (!c->scene_set || !c->accel_valid) return fail(c, PT_ERR_STATE, "pt_update_spheres: pt_set_scene + pt_build_accel first");
+    if (n != c->n) return fail(c, PT_ERR_INVALID_ARG, "pt_update_spheres: the sphere count must not change (use pt_set_scene)");
+    if (!c->gpu_builder) return fail(c, PT_ERR_UNSUPPORTED, "pt_update_spheres needs the device LBVH builder (no PT_FLAG_HOST_LBVH)");
+    for (uint32_t i = 0; i < n; i++)
+        if (!(spheres[i].r > 0.0f) || !std::isfinite(spheres[i].r) || !std::isfinite(spheres[i].cx) || !std::isfinite(spheres[i].cy) || !std::isfinite(spheres[i].cz))
+            return fail(c, PT_ERR_INVALID_ARG, "pt_update_spheres: sphere " + std::to_string(i) + " has a non-finite centre or non-positive radius");
+    PT_HIP(c, hipSetDevice(c->device));
+    Lane& L = c->lanes[c->next_lane];  // the lane the next render call will use
+    if (L.scene_n != n) {
+        PT_HIP(c, hipStreamSynchronize(L.stream));
+        free_lane_scene(L);
+        PT_HIP(c, hipMalloc(&L.d_sph, (size_t)n * sizeof(float4)));
+        PT_HIP(c, hipMalloc(&L.d_sph_sorted, (size_t)n * sizeof(float4)));
+        PT_HIP(c, hipMalloc(&L.d_nodes, (size_t)std::max(1u, n - 1) * sizeof(PtBvhNode)));
+        PT_HIP(c, hipMalloc(&L.d_refit_flags, (size_t)n * sizeof(uint32_t)));
+        PT_HIP(c, hipMalloc(&L.d_refit_hdr, 16 * sizeof(uint32_t)));
+        PT_HIP(c, hipHostMalloc(&L.h_stage, (size_t)n * sizeof(PtSphere)));
+        if (!L.ev_upload) PT_HIP(c, hipEventCreateWithFlags(&L.ev_upload, hipEventDisableTiming));
+        L.scene_n = n;
+    }
+    if (!L.scene_private) {
+        // first update on this lane: start from the master tree (topology + boxes), ordered after its build
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->n_nodes) PT_HIP(c, hipMemcpyAsync(L.d_nodes, c->d_nodes, (size_t)c->n_nodes * sizeof(PtBvhNode), hipMemcpyDeviceToDevice, L.stream));
+        L.scene_private = true;
+    } else {
+        PT_HIP(c, hipEventSynchronize(L.ev_upload));  // the previous upload from the staging buffer has been consumed
+    }
+    std::memcpy(L.h_stage, spheres, (size_t)n * sizeof(PtSphere));
+    PT_HIP(c, hipMemcpyAsync(L.d_sph, L.h_stage, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, L.stream));
+    PT_HIP(c, hipEventRecord(L.ev_upload, L.stream));
+    return PT_OK;
+}
+
+PtStatus pt_refit_accel(PtContext* c)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    Lane& L = c->lanes[c->next_lane];
+    if (!c->accel_valid || !L.scene_private) return fail(c, PT_ERR_STATE, "pt_refit_accel: call pt_update_spheres first");
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, lbvh_gpu_refit(c->gpu_builder, L.d_sph, c->n, reinterpret_cast<PtBvhNode*>(L.d_nodes), L.d_sph_sorted, c->d_sorted_id,
+                             L.d_refit_flags, L.d_refit_hdr, L.stream));
     return PT_OK;
 }
 

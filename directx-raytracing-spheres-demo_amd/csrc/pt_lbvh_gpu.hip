@@ -115,6 +115,11 @@ __global__ void gather_kernel(const float4* __restrict__ sph, const unsigned lon
     }
 }
 
+__global__ void gather_by_id_kernel(const float4* __restrict__ sph, const uint32_t* __restrict__ sorted_id, uint32_t n, float4* __restrict__ sorted)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) sorted[k] = sph[sorted_id[k]];
+}
+
 __device__ __forceinline__ int delta(const unsigned long long* __restrict__ keys, int n, int i, int j)
 {
     if (j < 0 || j >= n) return -1;
@@ -306,6 +311,22 @@ hipError_t lbvh_gpu_build(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode
     }
     info->pad = smax * 7.62939453125e-06f;
     return hipSuccess;
+}
+
+hipError_t lbvh_gpu_refit(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode* d_nodes, float4* d_sorted, const uint32_t* d_sorted_id,
+                          uint32_t* d_flags, uint32_t* d_hdr, hipStream_t stream)
+{
+    if (!b || !d_sph || n == 0 || !d_sorted || !d_sorted_id || !d_flags || !d_hdr || n > b->cap) return hipErrorInvalidValue;
+    const uint32_t threads = 256;
+    const uint32_t grid = (n + threads - 1) / threads < 4096u ? (n + threads - 1) / threads : 4096u;
+    hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, stream, d_hdr);
+    hipLaunchKernelGGL(bounds_kernel, dim3(grid), dim3(threads), 0, stream, d_sph, n, d_hdr);  // the padding follows the new bounds
+    hipLaunchKernelGGL(gather_by_id_kernel, dim3(grid), dim3(threads), 0, stream, d_sph, d_sorted_id, n, d_sorted);
+    if (n > 1) {
+        LB_CK(hipMemsetAsync(d_flags, 0, (size_t)n * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(refit_kernel, dim3(grid), dim3(threads), 0, stream, d_sorted, (int)n, d_nodes, b->leaf_parent, d_flags, d_hdr);
+    }
+    return hipGetLastError();
 }
 
 }  // namespace pt

@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-from .types import MATERIAL_DTYPE, SPHERE_DTYPE, PtCamera, PtSceneData
+from .abi_types import MATERIAL_DTYPE, SPHERE_DTYPE, PtCamera, PtSceneData
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 
@@ -22,6 +22,8 @@ class HostLib:
         self.lib.pth_scene.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(PtSceneData)]
         self.lib.pth_camera.restype = None
         self.lib.pth_camera.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(PtCamera)]
+        self.lib.pth_scene_at_time.restype = C.c_int
+        self.lib.pth_scene_at_time.argtypes = [C.c_uint32, C.c_double, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         self.lib.pth_halton.restype = C.c_float
         self.lib.pth_halton.argtypes = [C.c_uint32, C.c_uint32]
         self.lib.pth_random_floats.restype = None
@@ -40,6 +42,16 @@ class HostLib:
         if rc:
             raise ValueError(f"pth_scene failed ({rc})")
         return spheres, materials, sd
+
+    def scene_at_time(self, seed, time):
+        """Spheres of the demo scene at simulation time `time` (closed-form springs + Moon orbit, MyScene::SetTime)."""
+        n = C.c_uint32(0)
+        self.lib.pth_scene_at_time(seed, time, None, 0, C.byref(n))
+        spheres = np.zeros(n.value, dtype=SPHERE_DTYPE)
+        rc = self.lib.pth_scene_at_time(seed, time, spheres.ctypes.data, n.value, C.byref(n))
+        if rc:
+            raise ValueError(f"pth_scene_at_time failed ({rc})")
+        return spheres
 
     def camera(self, width, height, position=(0.0, 0.0, -15.0), look_at=None, hfov=math.pi / 2, jitter=True, jitter_index=0, jitter_count=8):
         """Demo camera (MyScene.ixx:90; HFOV 90 deg, MyAppData.h:177); jitter = Halton2D(index + 1) - 0.5 cycling mod 8."""

@@ -141,6 +141,53 @@ struct MySceneDesc : SceneDesc {
     }
 };
 
+// Scene with the demo's motion, closed form.  The reference integrates these with PhysX
+// (MyScene.ixx:351-396); without collisions the default forces have exact solutions:
+//   * HarmonicOscillator spheres: spring of period Spring::Period around PositionY, started at A cos(-x) with velocity
+//     -A w sin(-x) (MyScene.ixx:174-178,228) -> y(t) = PositionY + A cos(w t - x), w = 2 pi / Period (PhysX.h:30-34)
+//   * Moon: circular orbit of period 10 s around the Earth in the xz-plane (MyScene.ixx:240-248,270-277)
+//   * Earth / Star gravity on the other bodies is off by default (userData = false), their spin only matters with textures.
+struct MyScene : Scene {
+    explicit MyScene(unsigned seed = 0) { Load(MySceneDesc(seed)); m_initial = Desc.RenderObjects; }
+
+    bool IsStatic() const { return !m_isPhysXRunning; }
+    void SetRunning(bool running) { m_isPhysXRunning = running; }
+    double GetTime() const { return m_time; }
+
+    // Scene::Tick + Refresh (MyScene.ixx:310-349)
+    void Tick(double elapsedSeconds)
+    {
+        if (IsStatic()) return;
+        m_time += elapsedSeconds;
+        SetTime(m_time);
+    }
+
+    void SetTime(double time)
+    {
+        m_time = time;
+        constexpr float A = 0.5f, kTwoPi = 6.28318530717958647692f;
+        const float t = static_cast<float>(time);
+        for (size_t i = 0; i < Desc.RenderObjects.size(); i++) {
+            auto& o = Desc.RenderObjects[i];
+            const auto& o0 = m_initial[i];
+            if (o.Name == ObjectNames::HarmonicOscillator) {
+                const float omega = kTwoPi / Spring::Period;
+                o.Position.y = Spring::PositionY + A * std::cos(omega * t - o0.Position.x);
+            } else if (o.Name == ObjectNames::Moon) {
+                const float theta = kTwoPi / 10.0f * t;  // OrbitalPeriod = 10 (MyScene.ixx:244)
+                const float R = 4.0f;                     // |earth - moon| at t = 0
+                o.Position = { -R * std::cos(theta), o0.Position.y, R * std::sin(theta) };
+            }
+        }
+        Refresh();
+    }
+
+private:
+    std::vector<RenderObjectDesc> m_initial;
+    bool m_isPhysXRunning = true;
+    double m_time = 0;
+};
+
 // 16 spheres = 4 heroes + first 10 accepted grid spheres (seed) + Earth-like + Star ground.
 struct SmallSceneDesc : SceneDesc {
     explicit SmallSceneDesc(unsigned seed = 0)

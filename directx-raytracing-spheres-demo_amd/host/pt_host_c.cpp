@@ -62,6 +62,20 @@ void pth_camera(const float position[3], const float* look_at, float hfov, uint3
     *out = ToPt(camera);
 }
 
+// The demo scene at simulation time `time` seconds (closed-form motion, MyScene::SetTime): spheres only (the materials and
+// the object order are those of pth_scene(0, seed)).
+int pth_scene_at_time(uint32_t seed, double time, PtSphere* spheres, uint32_t capacity, uint32_t* count)
+{
+    MyScene scene(seed);
+    scene.SetTime(time);
+    const uint32_t n = scene.GetObjectCount();
+    if (count) *count = n;
+    if (!spheres) return 0;
+    if (capacity < n) return 1;
+    std::memcpy(spheres, scene.GetSpheres().data(), n * sizeof(PtSphere));
+    return 0;
+}
+
 float pth_halton(uint32_t index, uint32_t base) { return Halton(index, base); }
 
 // raw draws of the scene-generation RNG (Random.ixx mirror), for the host-logic tests

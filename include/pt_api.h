@@ -108,6 +108,13 @@ PtStatus pt_set_scene(PtContext *ctx, const PtSphere *spheres, const PtMaterial 
                       const PtSceneData *scene_data);
 /* Builds the LBVH over the current spheres.  info may be NULL. */
 PtStatus pt_build_accel(PtContext *ctx, PtAccelInfo *info);
+/* Moving spheres (the reference rebuilds its TLAS every frame while the physics runs, Source/App.cpp:605-608):
+ * pt_update_spheres uploads new centres / radii for the SAME n objects, pt_refit_accel recomputes every box of the
+ * existing tree bottom-up (the topology of the last pt_build_accel is kept; any valid BVH gives identical images, only
+ * traversal cost drifts -- call pt_set_scene + pt_build_accel again to rebuild).  Both are asynchronous and apply to the
+ * frame of the NEXT render call (with two frames in flight: to that frame's lane), so call them before every frame. */
+PtStatus pt_update_spheres(PtContext *ctx, const PtSphere *spheres, uint32_t n);
+PtStatus pt_refit_accel(PtContext *ctx);
 PtStatus pt_set_camera(PtContext *ctx, const PtCamera *camera);
 PtStatus pt_set_constants(PtContext *ctx, const PtGraphicsSettings *settings);
 

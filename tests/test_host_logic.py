@@ -139,3 +139,22 @@ def test_cpp_host_mirror_compiles_standalone(tmp_path):
                    'int main(){ dxrs::MySceneDesc d(0); dxrs::Scene s; s.Load(d); dxrs::Raytracing::GraphicsSettings g; g.Bounces = 8;'
                    ' static_assert(sizeof(dxrs::Material) == 64); static_assert(sizeof(dxrs::Camera) == 768); return s.GetObjectCount() == 441 ? 0 : 1; }\n')
     subprocess.run(["g++", "-std=c++20", "-fsyntax-only", "-Wall", "-I", hostdir, str(src)], check=True)
+
+
+def test_closed_form_motion(dxrs, host):
+    """MyScene::SetTime (SURVEY 8f N2): t = 0 is the static scene; the springs have period 3 s, the Moon 10 s; only the
+    oscillators and the Moon move; the Moon stays 4 units from the Earth."""
+    s0, _, _ = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    assert np.array_equal(host.scene_at_time(0, 0.0), s0)
+    a = host.scene_at_time(0, 1.234)
+    moved = (a["cx"] != s0["cx"]) | (a["cy"] != s0["cy"]) | (a["cz"] != s0["cz"])
+    assert not moved[:4].any() and not moved[-2:].any() and moved[4:-3].all() and moved[-3]  # heroes, Earth, Star fixed
+    assert np.array_equal(a["r"], s0["r"])
+    grid = slice(4, -3)
+    assert np.allclose(host.scene_at_time(0, 3.0)["cy"][grid], s0["cy"][grid], atol=2e-6)
+    assert np.allclose(a["cy"][grid], 0.5 + 0.5 * np.cos(2 * np.pi / 3 * 1.234 - s0["cx"][grid].astype(np.float64)), atol=2e-6)
+    for t in (0.0, 2.5, 5.0, 7.5):
+        m = host.scene_at_time(0, t)[-3]
+        assert abs(np.hypot(m["cx"], m["cz"]) - 4.0) < 1e-5 and m["cy"] == 4.0
+    m10, m0 = host.scene_at_time(0, 10.0)[-3], s0[-3]
+    assert abs(m10["cx"] - m0["cx"]) < 1e-4 and abs(m10["cz"] - m0["cz"]) < 1e-4
