@@ -179,8 +179,8 @@ PtStatus ensure_buffers(PtContext* c, Lane& L, size_t n_slots, bool need_spp, bo
         PT_HIP(c, hipHostMalloc(&L.h_prev_counts, n_counts * sizeof(uint32_t)));
         std::memset(L.h_prev_counts, 0, n_counts * sizeof(uint32_t));
         L.prev_signature = 0;
-        PT_HIP(c, hipMalloc(&L.d_counts, 2 * n_counts * sizeof(uint32_t)));
-        PT_HIP(c, hipMemsetAsync(L.d_counts, 0, 2 * n_counts * sizeof(uint32_t), L.stream));
+        PT_HIP(c, hipMalloc(&L.d_counts, 4 * n_counts * sizeof(uint32_t)));  // 2 parities x (queue sizes + work cursors)
+        PT_HIP(c, hipMemsetAsync(L.d_counts, 0, 4 * n_counts * sizeof(uint32_t), L.stream));
         PT_HIP(c, hipHostMalloc(&L.h_counts, n_counts * sizeof(uint32_t)));
         L.cap_counts = n_counts;
     }
@@ -269,8 +269,8 @@ uint64_t fixed_bytes(bool split, uint64_t slots, uint64_t pixels, uint64_t spp_p
 FrameCounters make_counters(const Lane& L, uint32_t parity)
 {
     FrameCounters fc{};
-    fc.counts = L.d_counts + (size_t)parity * L.cap_counts;
-    fc.fold_counts = L.d_counts + (size_t)(parity ^ 1u) * L.cap_counts;
+    fc.counts = L.d_counts + (size_t)parity * 2 * L.cap_counts;  // [queue sizes | work cursors]
+    fc.fold_counts = L.d_counts + (size_t)(parity ^ 1u) * 2 * L.cap_counts;
     fc.n_counts = (uint32_t)L.cap_counts - 1u;  // the whole allocation is summed / zeroed when folded
     fc.tail_rays = L.d_totals + 2 + parity;
     fc.fold_tail = L.d_totals + 2 + (parity ^ 1u);
@@ -437,7 +437,14 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
                 PT_HIP(c, bracket(3, [&] { return launch_tail(sv, pm, fp, qout, L.scratch, out, counts + k + 1, fc.tail_rays, grid_for(estimate(k + 1), kTailThreads, tail_cap), L.stream); }));
                 break;
             }
-            PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, counts + k + 1, grid_for(estimate(k + 1), trav_threads, trav_cap), L.stream); }));
+            if (!c->lds_scene && sv.n > 1 && env_u32("PT_RAY_REPLACEMENT", 1)) {
+                // persistent waves with ray replacement (heavy-tailed visit counts of large scenes)
+                uint32_t* cursor = counts + L.cap_counts + k + 1;
+                const uint32_t grid = std::min(grid_for(estimate(k + 1), 256u, c->num_cus * 8u), c->num_cus * env_u32("PT_DYN_BLOCKS_PER_CU", 6));
+                PT_HIP(c, bracket(1, [&] { return launch_traverse_dyn(sv, qout, counts + k + 1, cursor, grid, L.stream); }));
+            } else {
+                PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, counts + k + 1, grid_for(estimate(k + 1), trav_threads, trav_cap), L.stream); }));
+            }
         }
     }
     if (spp == 1) {

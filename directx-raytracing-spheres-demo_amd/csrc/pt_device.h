@@ -121,7 +121,8 @@ struct FrameParams {
 struct FrameCounters {
     uint32_t* counts;
     uint32_t* fold_counts;
-    uint32_t n_counts;  // counts[0..n_counts] are valid in both arrays
+    uint32_t n_counts;  // counts[0..n_counts] are valid in both arrays; each array is followed by n_counts + 1 work
+                        // cursors (cursor k hands out the rays of queue k to the ray-replacement traverse kernel)
     unsigned long long* tail_rays;
     unsigned long long* fold_tail;
     unsigned long long* totals;

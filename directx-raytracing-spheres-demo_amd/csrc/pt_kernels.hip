@@ -41,7 +41,7 @@ __device__ __forceinline__ void fold_counters(uint32_t* __restrict__ counts, uin
         *tail = 0ull;
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k <= n_counts; k += blockDim.x) counts[k] = 0u;
+    for (uint32_t k = threadIdx.x; k < 2u * (n_counts + 1u); k += blockDim.x) counts[k] = 0u;  // queue sizes + work cursors
 }
 
 // First kernel of a frame, block 0: fold the previous frame (other parity), publish this frame's queue-0 size.
@@ -232,6 +232,105 @@ __global__ __launch_bounds__(kTraverseThreads) void traverse_kernel(SceneView sv
         uint32_t id;
         closest_hit<StackT>(nodes, sph, ids, sv.n, make_f3(a.x, a.y, a.z), make_f3(b.x, b.y, b.z), 0.0f, kInf, stack, blockDim.x, t, id);
         q.hit[i] = make_uint2(as_uint(t), id);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ traverse, ray replacement
+// Closest hit for BVHs in global memory, where per-ray node visits have a heavy tail (2^20-sphere scene: mean 101, p99 407)
+// and a wave would otherwise idle until its slowest lane finishes: persistent waves pull rays from a work cursor and a
+// lane that finishes its ray is handed a new one as soon as fewer than kRefillBelow lanes of its wave are busy.
+constexpr uint32_t kRefillBelow = 44;
+
+template <typename StackT>
+__global__ __launch_bounds__(256) void traverse_dyn_kernel(SceneView sv, RayQueue q, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ cursor)
+{
+    extern __shared__ float4 smem[];
+    StackT* stack = reinterpret_cast<StackT*>(smem) + threadIdx.x;
+    const uint32_t stride = blockDim.x;
+    const uint32_t count = *count_ptr;
+    const float4* __restrict__ nodes = sv.nodes;
+    const float4* __restrict__ sph = sv.sph_sorted;
+    const uint32_t* __restrict__ ids = sv.sorted_id;
+    const uint32_t lane = lane_id();
+
+    bool active = false, more = true;
+    uint32_t idx = 0, sp = 0, best_id = kMissId;
+    int node = kTraversalDone;
+    f3 o = make_f3(0.f, 0.f, 0.f), d = make_f3(0.f, 0.f, 1.f);
+    float ix = 0.f, iy = 0.f, iz = 0.f, ox = 0.f, oy = 0.f, oz = 0.f, best = kInf;
+    for (;;) {
+        const unsigned long long act = __ballot(active);
+        if (more && (uint32_t)__popcll(act) < kRefillBelow) {
+            const unsigned long long idle = ~act;
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(cursor, n_idle);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t my = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && my < count) {
+                const float4 a = q.q0[my], b = q.q1[my];
+                o = make_f3(a.x, a.y, a.z); d = make_f3(b.x, b.y, b.z);
+                ix = fast_rcp(d.x); iy = fast_rcp(d.y); iz = fast_rcp(d.z);
+                ox = -o.x * ix; oy = -o.y * iy; oz = -o.z * iz;
+                node = 0; sp = 0; best = kInf; best_id = kMissId;
+                idx = my; active = true;
+            }
+            more = base + n_idle < count;
+        }
+        if (!__ballot(active)) break;
+        bool finished = false;
+        if (active) {
+            while (node >= 0) {
+                const float4 n0 = nodes[node * 4 + 0];
+                const float4 n1 = nodes[node * 4 + 1];
+                const float4 n2 = nodes[node * 4 + 2];
+                const float4 n3 = nodes[node * 4 + 3];
+                float ax = pt_fma(n0.x, ix, ox), bx = pt_fma(n0.w, ix, ox);
+                float ay = pt_fma(n0.y, iy, oy), by = pt_fma(n1.x, iy, oy);
+                float az = pt_fma(n0.z, iz, oz), bz = pt_fma(n1.y, iz, oz);
+                const float tn0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+                const float tf0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
+                ax = pt_fma(n1.z, ix, ox); bx = pt_fma(n2.y, ix, ox);
+                ay = pt_fma(n1.w, iy, oy); by = pt_fma(n2.z, iy, oy);
+                az = pt_fma(n2.x, iz, oz); bz = pt_fma(n2.w, iz, oz);
+                const float tn1 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+                const float tf1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));
+                const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+                const int c0 = __builtin_bit_cast(int, n3.x), c1 = __builtin_bit_cast(int, n3.y);
+                if (h0 && h1) {
+                    const bool swap = tn1 < tn0;
+                    stack[sp * stride] = stack_encode<StackT>(swap ? c0 : c1);
+                    sp++;
+                    node = swap ? c1 : c0;
+                } else if (h0) {
+                    node = c0;
+                } else if (h1) {
+                    node = c1;
+                } else if (sp == 0) {
+                    node = kTraversalDone;
+                } else {
+                    sp--;
+                    node = stack_decode(stack[sp * stride]);
+                }
+            }
+            if (node == kTraversalDone) {
+                finished = true;
+            } else {
+                const uint32_t k = ~(uint32_t)node;
+                const float4 s = sph[k];
+                float t;
+                if (intersect_sphere(o, d, 0.0f, kInf, make_f3(s.x, s.y, s.z), s.w, t)) {
+                    const uint32_t id = ids[k];
+                    if (t < best || (t == best && best_id != kMissId && id < best_id)) { best = t; best_id = id; }
+                }
+                if (sp == 0) finished = true;
+                else { sp--; node = stack_decode(stack[sp * stride]); }
+            }
+        }
+        if (active && finished) {
+            q.hit[idx] = make_uint2(as_uint(best), best_id);
+            active = false;
+        }
     }
 }
 
@@ -676,6 +775,15 @@ hipError_t launch_primary(const SceneView& sv, const PixelMap& pm, const FramePa
 hipError_t launch_traverse(const SceneView& sv, const RayQueue& q, const uint32_t* count_ptr, uint32_t grid, hipStream_t stream)
 {
     PT_DISPATCH_TRAVERSE(traverse_kernel, grid, stream, sv, q, count_ptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_traverse_dyn(const SceneView& sv, const RayQueue& q, const uint32_t* count_ptr, uint32_t* cursor, uint32_t grid, hipStream_t stream)
+{
+    const bool small = sv.n_nodes < 32767u;
+    const uint32_t lds = 256u * sv.stack_depth * (small ? 2u : 4u);
+    if (small) hipLaunchKernelGGL((traverse_dyn_kernel<uint16_t>), dim3(grid), dim3(256), lds, stream, sv, q, count_ptr, cursor);
+    else hipLaunchKernelGGL((traverse_dyn_kernel<uint32_t>), dim3(grid), dim3(256), lds, stream, sv, q, count_ptr, cursor);
     return hipGetLastError();
 }
 
