@@ -35,8 +35,9 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--scene", choices=["demo", "small", "procedural"], default="demo")
     ap.add_argument("--spheres", type=int, default=1 << 20, help="sphere count of the procedural scene")
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2],
-                    help="2: consecutive frames alternate between two streams / output buffers so one frame's tail overlaps the next frame's start")
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=range(0, 9),
+                    help="consecutive frames rotate over this many streams / output buffers so one frame's latency-bound tail overlaps the next "
+                         "frames' start; 0 = auto (3 on one GPU, 4 when the frame is split over several)")
     ap.add_argument("--animate", action="store_true",
                     help="demo scene in motion (closed-form springs + Moon orbit, 1/60 s per frame): per-frame sphere upload + LBVH refit inside the timed region")
     ap.add_argument("--force-tiles", action="store_true", help="run the tile / gather / un-swizzle path even with one rank (rehearsal of the N > 1 path)")
@@ -76,19 +77,22 @@ def main():
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
-    r = dxrs_amd.Renderer(device=local_rank, stream=stream, flags=0 if args.frames_in_flight < 2 else dxrs_amd.types.PT_FLAG_TWO_FRAMES_IN_FLIGHT)
+    if args.frames_in_flight == 0:
+        args.frames_in_flight = 4 if (world > 1 or args.force_tiles) else 3
+    nbuf = args.frames_in_flight
+    r = dxrs_amd.Renderer(device=local_rank, stream=stream, frames_in_flight=nbuf)
     accel = r.set_scene(spheres, materials, sd)
     r.set_partition(rank, world)
     gs = graphics_settings(w, h, frame_index=0, bounces=args.bounces, spp=args.spp)
     r.set_constants(gs)
     ts = 32
-    # double-buffered outputs: frame k writes buffer k % 2 (the swap chain of the reference, two frames in flight)
+    # multi-buffered outputs: frame k writes buffer k % frames_in_flight (the reference's swap chain, generalised)
     if not tiled:
-        frames = [torch.empty((h * w, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        frames = [torch.empty((h * w, 4), dtype=torch.float32, device=dev) for _ in range(nbuf)]
         frame = frames[0]
     else:
         max_tiles = r.tiles_count(0)
-        packeds = [torch.zeros((max_tiles * ts * ts, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        packeds = [torch.zeros((max_tiles * ts * ts, 4), dtype=torch.float32, device=dev) for _ in range(nbuf)]
         packed = packeds[0]
         if rank == 0:
             gathered = torch.empty((world, max_tiles * ts * ts, 4), dtype=torch.float32, device=dev)
@@ -109,12 +113,22 @@ def main():
         r.set_camera(cams[k % 8])
         r.set_constants(gs)
         if not tiled:
-            r.render_device(frames[k % 2].data_ptr())
+            r.render_device(frames[k % nbuf].data_ptr())
         else:
-            r.render_tiles(packeds[k % 2].data_ptr())
-            dist.gather(packeds[k % 2], gather_list if rank == 0 else None, dst=0)
+            r.render_tiles(packeds[k % nbuf].data_ptr())
+            dist.gather(packeds[k % nbuf], gather_list if rank == 0 else None, dst=0)
             if rank == 0:
                 r.unpack_tiles(gathered.data_ptr(), max_tiles, frame.data_ptr())
+
+    def step_on(rr, k):
+        """one frame on renderer rr (this rank's share, no gather): used for the exclusive-kernel measurement"""
+        gs.FrameIndex = k
+        rr.set_camera(cams[k % 8])
+        rr.set_constants(gs)
+        if not tiled:
+            rr.render_device(frames[0].data_ptr())
+        else:
+            rr.render_tiles(packeds[0].data_ptr())
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -224,14 +238,35 @@ def main():
                 traffic = pmc[key]["hbm_bytes_per_launch"]
         except Exception:
             pass
+        # the same kernel class running ALONE on the GPU (one frame at a time, a few frames): with several frames in flight the
+        # launches of consecutive frames share the machine, which stretches every per-launch duration above
+        excl = None
+        if args.frames_in_flight > 1 and not split:
+            r1 = dxrs_amd.Renderer(device=local_rank, stream=stream, frames_in_flight=1)
+            r1.set_scene(spheres, materials, sd); r1.set_partition(rank, world); r1.set_constants(gs)
+            for k in range(3):
+                step_on(r1, k)
+            r1.set_profiling(True)
+            for k in range(20):
+                step_on(r1, args.warmup + k)
+            p1 = r1.profile(reset=True)
+            r1.close()
+            ms1, n1 = (p1.ms_tail, p1.tail_launches) if "loop" in name else (p1.ms_traverse, p1.traverse_launches)
+            if n1 and ms1 > 0:
+                excl = {"avg_launch_ms": ms1 / n1, "achieved": (b / n) / (ms1 / n1 * 1e-3) / 1e9}
+                excl["frac"] = excl["achieved"] / HBM_PEAK_GBS
         result["roofline"] = {
             "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "bytes_per_launch": b / max(n, 1), "avg_launch_ms": ms / max(n, 1), "launches_per_frame": n / n_f,
             "compacting_ms_per_frame": prof.ms_traverse / n_f, "shade_ms_per_frame": prof.ms_shade / n_f, "loop_ms_per_frame": prof.ms_tail / n_f,
             "ms_per_step_with_events": elapsed_ev / n_f * 1e3,
-            "note": "per-launch HIP events over a second timed region of the same K steps; with two frames in flight launches of "
-                    "consecutive frames overlap, so per-launch durations add up to more than ms_per_step",
+            "exclusive": excl,
+            "sustained_gbs": (b / n_f) / (elapsed / args.steps) / 1e9,
+            "note": "achieved/frac: per-launch HIP events over a second timed region of the same K steps (they agree with the rocprofv3 "
+                    "kernel-trace averages of this command); with N frames in flight the launches of consecutive frames overlap and share "
+                    "the GPU, so each lasts longer than when it runs alone ('exclusive': one frame at a time); 'sustained_gbs' = this "
+                    "kernel class's algorithmic bytes per frame / ms_per_step",
         }
 
     # ---- CPU baseline: the scalar oracle on this node's host cores, bounded sample of the same frame (rank 0, N = 1)

@@ -49,7 +49,7 @@ class PtRect(C.Structure):
 
 
 class PtConfig(C.Structure):
-    _fields_ = [("device", C.c_int32), ("tile_size", C.c_uint32), ("stream", C.c_uint64), ("flags", C.c_uint32), ("_reserved", C.c_uint32)]
+    _fields_ = [("device", C.c_int32), ("tile_size", C.c_uint32), ("stream", C.c_uint64), ("flags", C.c_uint32), ("frames_in_flight", C.c_uint32)]
 
 
 class PtAccelInfo(C.Structure):

@@ -127,9 +127,9 @@ def load_hip():
 class Renderer:
     """One PtContext.  Methods mirror the C-ABI one to one; errors raise PtError with pt_last_error()."""
 
-    def __init__(self, device=0, flags=0, stream=0, tile_size=0, lib=None):
+    def __init__(self, device=0, flags=0, stream=0, tile_size=0, lib=None, frames_in_flight=0):
         self._lib = (lib or load_hip()).lib
-        cfg = PtConfig(device=device, tile_size=tile_size, stream=stream, flags=flags)
+        cfg = PtConfig(device=device, tile_size=tile_size, stream=stream, flags=flags, frames_in_flight=frames_in_flight)
         ctx = C.c_void_p()
         st = self._lib.pt_create(C.byref(cfg), C.byref(ctx))
         if st != 0:

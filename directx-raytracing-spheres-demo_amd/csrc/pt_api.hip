@@ -61,7 +61,7 @@ struct Lane {
     uint32_t scene_n = 0;             // sphere count the private copy was allocated for
     bool scene_private = false;
 };
-constexpr uint32_t kMaxLanes = 2;
+constexpr uint32_t kMaxLanes = 8;
 
 struct PtContext {
     int device = 0;
@@ -102,7 +102,7 @@ struct PtContext {
     uint32_t n_lanes = 1;
     uint32_t next_lane = 0;
     uint32_t last_lane = 0;
-    hipEvent_t ev_in[2] = { nullptr, nullptr };  // markers on `stream` at the start of the last two render calls
+    hipEvent_t ev_in[kMaxLanes] = {};  // markers on `stream` at the start of the last n_lanes render calls
     uint64_t calls = 0;
     float4* d_out = nullptr;
     size_t cap_out = 0;
@@ -333,12 +333,13 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     PtStatus st = ensure_buffers(c, L, pm.n_slots, spp > 1, split, wf_cap + 2);
     if (st != PT_OK) return st;
     if (L.stream != c->stream) {
-        // Two frames in flight.  The caller alternates between two output buffers, so this frame may start as soon as
-        // the consumer of ITS buffer (queued on the caller's stream before the previous render call) has run: wait for
-        // the marker recorded at the start of the previous call -- not for the previous frame itself, whose completion
-        // wait was queued on the caller's stream after that marker.
-        PT_HIP(c, hipEventRecord(c->ev_in[c->calls & 1], c->stream));
-        PT_HIP(c, hipStreamWaitEvent(L.stream, c->ev_in[c->calls ? (c->calls - 1) & 1 : 0], 0));
+        // N frames in flight.  The caller rotates over N output buffers, so this frame may start as soon as the consumer of
+        // ITS buffer (queued on the caller's stream right after the render call N calls ago, i.e. before the call N-1 calls
+        // ago) has run: wait for the marker recorded at the start of that call -- not for the frames in between, whose
+        // completion waits were queued on the caller's stream after that marker.
+        const uint64_t nl = c->n_lanes;
+        PT_HIP(c, hipEventRecord(c->ev_in[c->calls % nl], c->stream));
+        PT_HIP(c, hipStreamWaitEvent(L.stream, c->ev_in[c->calls >= nl - 1 ? (c->calls - (nl - 1)) % nl : 0], 0));
         c->calls++;
     }
 
@@ -535,9 +536,10 @@ PtStatus pt_create(const PtConfig* config, PtContext** out_ctx)
         c->own_stream = true;
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess
-        || hipEventCreateWithFlags(&c->ev_in[0], hipEventDisableTiming) != hipSuccess
-        || hipEventCreateWithFlags(&c->ev_in[1], hipEventDisableTiming) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
-    c->n_lanes = (config->flags & PT_FLAG_TWO_FRAMES_IN_FLIGHT) ? kMaxLanes : 1u;
+        ) { pt_destroy(c); return PT_ERR_HIP; }
+    c->n_lanes = config->frames_in_flight > 1 ? std::min(config->frames_in_flight, kMaxLanes) : ((config->flags & PT_FLAG_TWO_FRAMES_IN_FLIGHT) ? 2u : 1u);
+    for (uint32_t i = 0; i < c->n_lanes; i++)
+        if (hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
     for (uint32_t i = 0; i < c->n_lanes; i++) {
         Lane& L = c->lanes[i];
         if (c->n_lanes == 1) L.stream = c->stream;

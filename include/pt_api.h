@@ -50,7 +50,7 @@ typedef struct PtConfig {
     uint64_t stream;        /* hipStream_t to run on (e.g. a torch.cuda.Stream's handle); 0 -> context-owned stream, or the
                                legacy default (null) stream with PT_FLAG_DEFAULT_STREAM */
     uint32_t flags;         /* PT_FLAG_* */
-    uint32_t _reserved;
+    uint32_t frames_in_flight; /* 0 or 1: one frame at a time; 2..8: that many lanes (see PT_FLAG_TWO_FRAMES_IN_FLIGHT) */
 } PtConfig;
 
 enum {
@@ -59,10 +59,11 @@ enum {
     PT_FLAG_HOST_LBVH = 4u,      /* build the LBVH on the host instead of on the GPU (debug / A-B) */
     PT_FLAG_SPLIT_KERNELS = 8u,  /* separate traverse / shade kernels with a hit stream instead of the fused bounce kernel */
     PT_FLAG_DEFAULT_STREAM = 32u, /* with stream == 0: run on the legacy default stream instead of a context-owned one */
-    PT_FLAG_TWO_FRAMES_IN_FLIGHT = 16u /* consecutive render calls alternate between two internal streams (and two sets of
-                                          work buffers) so that the latency-bound tail of one frame overlaps the start of
-                                          the next.  The caller must alternate between two output buffers; whatever it
-                                          queues on `stream` after a render call is ordered after that frame. */
+    PT_FLAG_TWO_FRAMES_IN_FLIGHT = 16u /* frames in flight (same as PtConfig.frames_in_flight = 2; that field allows up to 8):
+                                          consecutive render calls rotate over N internal streams ("lanes", each with its own
+                                          work buffers) so that the latency-bound tail of one frame overlaps the start of the
+                                          next ones.  The caller must rotate over N output buffers; whatever it queues on
+                                          `stream` after a render call is ordered after that frame. */
 };
 
 typedef struct PtAccelInfo {

@@ -60,10 +60,11 @@ def test_full_frame_determinism_and_counts(dxrs, host, renderer):
     assert a[:8, :, 2].min() > a[:8, :, 0].max()
 
 
-def test_two_frames_in_flight(dxrs, host, renderer):
-    """PT_FLAG_TWO_FRAMES_IN_FLIGHT: consecutive frames run on two internal streams with two sets of work buffers and
-    overlap on the GPU; with the caller alternating two output buffers every frame is bit-identical to the
-    one-frame-at-a-time render, and the device-accumulated ray totals agree."""
+@pytest.mark.parametrize("lanes", [2, 3, 5])
+def test_frames_in_flight(dxrs, host, renderer, lanes):
+    """Frames in flight: consecutive frames run on N internal streams with N sets of work buffers and overlap on the
+    GPU; with the caller rotating over N output buffers every frame is bit-identical to the one-frame-at-a-time render,
+    and the device-accumulated ray totals agree."""
     import torch
     spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
     w, h, n_frames = 640, 360, 12
@@ -77,18 +78,19 @@ def test_two_frames_in_flight(dxrs, host, renderer):
         img, st = renderer.render()
         ref.append(img); ref_rays += st.rays
     tstream = torch.cuda.Stream()  # the caller's stream: consumers queued on it are ordered after each frame
-    r2 = dxrs.Renderer(stream=tstream.cuda_stream, flags=dxrs.types.PT_FLAG_TWO_FRAMES_IN_FLIGHT)
+    r2 = dxrs.Renderer(stream=tstream.cuda_stream, flags=dxrs.types.PT_FLAG_TWO_FRAMES_IN_FLIGHT) if lanes == 2 else \
+        dxrs.Renderer(stream=tstream.cuda_stream, frames_in_flight=lanes)
     try:
         with torch.cuda.stream(tstream):
             r2.set_scene(spheres, materials, sd)
-            bufs = [torch.empty((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+            bufs = [torch.empty((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(lanes)]
             keep = []
             r2.totals(reset=True)
             for k in range(n_frames):
                 gs.FrameIndex = k
                 r2.set_camera(cams[k % 8]); r2.set_constants(gs)
-                r2.render_device(bufs[k % 2].data_ptr())
-                keep.append(bufs[k % 2].clone())  # a consumer on the caller's stream: ordered after frame k, before frame k + 2
+                r2.render_device(bufs[k % lanes].data_ptr())
+                keep.append(bufs[k % lanes].clone())  # a consumer on the caller's stream: ordered after frame k, before frame k + lanes
             torch.cuda.synchronize()
             tot = r2.totals()
             assert tot.rays == ref_rays
