@@ -67,3 +67,34 @@ def test_rr_off_and_zero_bounces(dxrs, host, oracle, renderer):
         img, stats, ref, ostats = _render_both(dxrs, host, oracle, renderer, scene, 160, 90, bounces, 1, rr=rr)
         assert stats.rays == ostats.rays
         assert count_mismatch(img, ref) == 0
+
+
+@pytest.mark.parametrize("w,h,rect", [(1, 1, None), (7, 5, None), (9, 17, (8, 16, 1, 1)), (100, 3, (93, 0, 7, 3)), (33, 65, None)])
+def test_ragged_and_tiny_frames(dxrs, host, oracle, renderer, w, h, rect):
+    """Frame sizes that are not multiples of the 8x8 wave block, 1x1 frames and 1x1 rects at the far corner."""
+    scene = host.scene(dxrs.host.SCENE_SMALL, seed=0)
+    img, stats, ref, ostats = _render_both(dxrs, host, oracle, renderer, scene, w, h, 4, 2, rect=rect)
+    assert img.shape == ref.shape and stats.rays == ostats.rays and stats.pixels == img.shape[0] * img.shape[1]
+    assert count_mismatch(img, ref) == 0
+
+
+def test_more_ranks_than_tiles(dxrs, host, renderer):
+    """A rank that owns no tile renders nothing and reports zero work."""
+    import torch
+    scene = host.scene(dxrs.host.SCENE_SMALL, seed=0)
+    renderer.set_scene(*scene); renderer.set_camera(host.camera(40, 40)); renderer.set_constants(dxrs.types.graphics_settings(40, 40, bounces=2))
+    try:
+        renderer.set_partition(5, 8)  # 2 x 2 tiles: ranks 4..7 own nothing
+        assert renderer.tiles_count(5) == 0 and renderer.tiles_count(3) == 1
+        buf = torch.zeros((1024, 4), dtype=torch.float32, device="cuda")
+        st = renderer.render_tiles(buf.data_ptr(), want_stats=True)
+        assert st.rays == 0 and float(buf.abs().sum()) == 0.0
+    finally:
+        renderer.set_partition(0, 1)
+
+
+def test_deep_paths(dxrs, host, oracle, renderer):
+    """Many bounces with Russian roulette off: long transmission chains inside the glass spheres (looping pass)."""
+    scene = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    img, stats, ref, ostats = _render_both(dxrs, host, oracle, renderer, scene, 1920, 1080, 40, 1, rect=(900, 420, 128, 96), rr=False)
+    assert stats.rays == ostats.rays and count_mismatch(img, ref) == 0

@@ -21,5 +21,5 @@ def run(lib, env, reps=30):
     return "total %.3f wf %.3f loop %.3f rays %d"%(np.median(tt), np.median(tr), np.median(tl), st.rays)
 print("full       ", run(None, {}))
 for a,name in ((1,"no BSDF    "),(2,"no traverse"),(3,"neither    ")):
-    lib = HipLib(os.path.join(os.getcwd(),"scratch","libpt_ablate%d.so"%a))
+    lib = HipLib(os.path.join(os.getcwd(),"tools","experiments","libpt_ablate%d.so"%a))
     print(name, run(lib, {}))
