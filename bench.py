@@ -287,8 +287,13 @@ def main():
                 o_time += time.perf_counter() - t0c
                 o_rays += int(ost.rays)
                 o_frames += 1
+            # single-thread figure: every 16th row of one frame
+            t0c = time.perf_counter()
+            _, ost1 = oracle.render(spheres, materials, sd, cams[args.warmup % 8], gs, row_step=16, threads=1)
+            t_single = time.perf_counter() - t0c
             result["cpu_baseline"] = {
                 "value": o_rays / o_time / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                "single_thread_value": ost1.rays / t_single / 1e6,
                 "sample": f"{o_frames} frame(s) of the same {w}x{h} workload (FrameIndex {args.warmup}..{args.warmup + o_frames - 1}"
                           + (f", every {args.cpu_row_step}th row" if args.cpu_row_step > 1 else "")
                           + f"): {o_rays} rays in {o_time:.2f} s wall = {o_time * cores:.1f} s of CPU work, scalar C oracle, brute-force O(N) intersection "
