@@ -196,7 +196,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.scene} sphere scene (seed 0, {len(spheres)} spheres), {w}x{h}, {args.spp} spp, {args.bounces} bounces, RR on, sky env"
+                "workload": f"{args.scene} sphere scene (seed {1 if args.scene == 'procedural' else 0}, {len(spheres)} spheres), {w}x{h}, {args.spp} spp, {args.bounces} bounces, RR on, sky env"
                             + (f", 32x32 tiles interleaved over {world} GPU(s) + RCCL gather to rank 0" if tiled else ""),
                 "frames_in_flight": args.frames_in_flight,
                 "animated": bool(args.animate),

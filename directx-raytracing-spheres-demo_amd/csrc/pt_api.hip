@@ -822,7 +822,10 @@ PtStatus pt_render_tiles(PtContext* c, void* out_device_packed, PtStats* stats)
     pm.tiles_total = pm.tiles_x * ((h + ts - 1) / ts);
     pm.rank = c->rank; pm.world = c->world;
     const uint64_t slots = (uint64_t)pt_tiles_count(c, c->rank) * ts * ts;
-    if (slots == 0) return PT_OK;
+    if (slots == 0) {  // this rank owns no tile of the frame
+        if (stats) std::memset(stats, 0, sizeof *stats);
+        return PT_OK;
+    }
     if (slots > 0xFFFFFFFFull) return fail(c, PT_ERR_INVALID_ARG, "pt_render_tiles: too many pixels");
     pm.n_slots = (uint32_t)slots;
     return render_common(c, pm, count_tile_pixels(w, h, ts, c->rank, c->world), static_cast<float4*>(out_device_packed), stats);

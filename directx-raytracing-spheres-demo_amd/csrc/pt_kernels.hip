@@ -98,7 +98,7 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
     const float ix = fast_rcp(d.x), iy = fast_rcp(d.y), iz = fast_rcp(d.z);
     const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
     int node = 0;
-    uint32_t sp = 0;
+    uint32_t sp = 0;  // stack offset in elements: a multiple of `stride` (entry e of this lane lives at stack[e * stride])
     for (;;) {
         while (node >= 0) {
             if (kCount) n_nodes_visited++;
@@ -122,8 +122,8 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
             if (h0 && h1) {
                 const bool swap = tn1 < tn0;
                 const int near_c = swap ? c1 : c0, far_c = swap ? c0 : c1;
-                stack[sp * stride] = stack_encode<StackT>(far_c);
-                sp++;
+                stack[sp] = stack_encode<StackT>(far_c);
+                sp += stride;
                 node = near_c;
             } else if (h0) {
                 node = c0;
@@ -132,8 +132,8 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
             } else if (sp == 0) {
                 node = kTraversalDone;
             } else {
-                sp--;
-                node = stack_decode(stack[sp * stride]);
+                sp -= stride;
+                node = stack_decode(stack[sp]);
             }
         }
         if (node == kTraversalDone) break;
@@ -148,8 +148,8 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
             }
         }
         if (sp == 0) break;
-        sp--;
-        node = stack_decode(stack[sp * stride]);
+        sp -= stride;
+        node = stack_decode(stack[sp]);
     }
     // t < tmax is required by intersect_sphere's contract: best starts at tmax and only shrinks
     t_out = best; id_out = best_id;
@@ -299,8 +299,8 @@ __global__ __launch_bounds__(256) void traverse_dyn_kernel(SceneView sv, RayQueu
                 const int c0 = __builtin_bit_cast(int, n3.x), c1 = __builtin_bit_cast(int, n3.y);
                 if (h0 && h1) {
                     const bool swap = tn1 < tn0;
-                    stack[sp * stride] = stack_encode<StackT>(swap ? c0 : c1);
-                    sp++;
+                    stack[sp] = stack_encode<StackT>(swap ? c0 : c1);
+                    sp += stride;
                     node = swap ? c1 : c0;
                 } else if (h0) {
                     node = c0;
@@ -309,8 +309,8 @@ __global__ __launch_bounds__(256) void traverse_dyn_kernel(SceneView sv, RayQueu
                 } else if (sp == 0) {
                     node = kTraversalDone;
                 } else {
-                    sp--;
-                    node = stack_decode(stack[sp * stride]);
+                    sp -= stride;
+                    node = stack_decode(stack[sp]);
                 }
             }
             if (node == kTraversalDone) {
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void traverse_dyn_kernel(SceneView sv, RayQueu
                     if (t < best || (t == best && best_id != kMissId && id < best_id)) { best = t; best_id = id; }
                 }
                 if (sp == 0) finished = true;
-                else { sp--; node = stack_decode(stack[sp * stride]); }
+                else { sp -= stride; node = stack_decode(stack[sp]); }
             }
         }
         if (active && finished) {
