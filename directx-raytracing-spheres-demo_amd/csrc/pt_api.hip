@@ -58,6 +58,7 @@ struct Lane {
     uint32_t* d_refit_hdr = nullptr;
     PtSphere* h_stage = nullptr;      // pinned upload staging
     hipEvent_t ev_upload = nullptr;   // the last upload from h_stage has been consumed
+    hipEvent_t ev_poll[4] = {};       // queue-size read-backs of the last passes (spp > 1 lagged polling)
     uint32_t scene_n = 0;             // sphere count the private copy was allocated for
     bool scene_private = false;
 };
@@ -385,10 +386,20 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     auto poll = [&](size_t k, bool& empty, bool& go_loop) -> PtStatus {
         empty = false;
         if (spp > 1) {
-            PT_HIP(c, hipMemcpyAsync(L.h_counts, counts + k + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, L.stream));
-            PT_HIP(c, hipStreamSynchronize(L.stream));
-            empty = L.h_counts[0] == 0;
-            go_loop = L.h_counts[0] < tail_threshold || k + 2 >= wf_cap;
+            // Lagged polling: read back the size of queue k+1 asynchronously, but decide on the size the queue had kPollLag
+            // passes ago, whose copy has long completed -- the GPU never idles waiting for the host.  Queue sizes only
+            // shrink (a path emits at most one ray per pass), so a stale size is an upper bound: "was already empty" and
+            // "was already below the threshold" stay true; the cost of staleness is at most kPollLag cheap extra passes.
+            constexpr size_t kPollLag = 2;
+            PT_HIP(c, hipMemcpyAsync(L.h_counts + k + 1, counts + k + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, L.stream));
+            PT_HIP(c, hipEventRecord(L.ev_poll[k & 3], L.stream));
+            go_loop = k + 2 >= wf_cap;
+            if (k >= kPollLag) {
+                PT_HIP(c, hipEventSynchronize(L.ev_poll[(k - kPollLag) & 3]));
+                const uint32_t v = L.h_counts[k - kPollLag + 1];
+                empty = v == 0;
+                go_loop = go_loop || v < tail_threshold;
+            }
         } else {
             go_loop = k >= tail_after || k + 2 >= wf_cap;
         }
@@ -544,7 +555,9 @@ PtStatus pt_create(const PtConfig* config, PtContext** out_ctx)
         Lane& L = c->lanes[i];
         if (c->n_lanes == 1) L.stream = c->stream;
         else if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
-        if (hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) != hipSuccess
+        bool ok = true;
+        for (auto& e : L.ev_poll) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (!ok || hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) != hipSuccess
             || hipMalloc(&L.d_totals, 4 * sizeof(unsigned long long)) != hipSuccess
             || hipMemsetAsync(L.d_totals, 0, 4 * sizeof(unsigned long long), L.stream) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
     }
@@ -561,6 +574,7 @@ void pt_destroy(PtContext* c)
         free_lane_buffers(L);
         free_lane_scene(L);
         if (L.ev_upload) (void)hipEventDestroy(L.ev_upload);
+        for (auto& e : L.ev_poll) if (e) (void)hipEventDestroy(e);
         free_dev(L.d_counts); free_dev(L.d_totals);
         if (L.h_counts) (void)hipHostFree(L.h_counts);
         if (L.h_prev_counts) (void)hipHostFree(L.h_prev_counts);
