@@ -21,6 +21,18 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// Reciprocal of a ray-direction component for the slab test t = fma(plane, inv, -o * inv).  A zero (or denormal-tiny)
+// component would give inv = inf and then inf - inf = NaN for the planes on one side of the origin, and fmax(-inf, NaN)
+// = -inf would wrongly close the slab: the component is replaced by +-1e-30, which keeps every product finite (scene
+// coordinates are far below 1e8) and makes the slab interval (-huge, +huge) when the origin lies between the planes and
+// empty otherwise -- the exact behaviour of an axis-parallel ray.  Found by tests/test_gpu_fuzz.py (centre column of
+// an odd-width frame with zero jitter: d.x == 0).
+__device__ __forceinline__ float slab_rcp(float d)
+{
+    const float kTiny = 1e-30f;
+    return fast_rcp(__builtin_fabsf(d) < kTiny ? __builtin_copysignf(kTiny, d) : d);
+}
+
 // Called by every thread of ONE block: fold a finished frame's counters (queue sizes 1..n + its tail counter) into
 // the running totals and leave them zeroed.
 __device__ __forceinline__ void fold_counters(uint32_t* __restrict__ counts, uint32_t n_counts, unsigned long long* __restrict__ tail,
@@ -95,7 +107,7 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
         t_out = best; id_out = best_id;
         return;
     }
-    const float ix = fast_rcp(d.x), iy = fast_rcp(d.y), iz = fast_rcp(d.z);
+    const float ix = slab_rcp(d.x), iy = slab_rcp(d.y), iz = slab_rcp(d.z);
     const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
     int node = 0;
     uint32_t sp = 0;  // stack offset in elements: a multiple of `stride` (entry e of this lane lives at stack[e * stride])
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(256) void traverse_dyn_kernel(SceneView sv, RayQueu
             if (!active && my < count) {
                 const float4 a = q.q0[my], b = q.q1[my];
                 o = make_f3(a.x, a.y, a.z); d = make_f3(b.x, b.y, b.z);
-                ix = fast_rcp(d.x); iy = fast_rcp(d.y); iz = fast_rcp(d.z);
+                ix = slab_rcp(d.x); iy = slab_rcp(d.y); iz = slab_rcp(d.z);
                 ox = -o.x * ix; oy = -o.y * iy; oz = -o.z * iz;
                 node = 0; sp = 0; best = kInf; best_id = kMissId;
                 idx = my; active = true;

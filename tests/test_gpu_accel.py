@@ -27,6 +27,13 @@ def make_rays(spheres, n, seed):
     nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
     o[k] = c[pick[k]] + nrm[k] * r[pick[k], None] * (1 + 2 ** -14)
     d32 = d.astype(np.float32)
+    # axis-parallel and plane-parallel rays: direction components that are exactly +0 / -0 (the slab test divides by
+    # them; a frame of odd width with zero jitter has a whole column of such rays)
+    ax = np.arange(n) % 16 == 3
+    zero_mask = rng.integers(1, 7, n)  # bit c set -> component c is zeroed (never all three)
+    for c in range(3):
+        z = ax & ((zero_mask >> c) & 1).astype(bool)
+        d32[z, c] = np.where(rng.random(int(z.sum())) < 0.5, np.float32(0.0), np.float32(-0.0))
     d32 /= np.linalg.norm(d32.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
     return o.astype(np.float32), d32
 
