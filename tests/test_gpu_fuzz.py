@@ -1,6 +1,8 @@
 """Randomised scenes through the whole pipeline vs the CPU oracle: overlapping / nested / coincident spheres (tie-break by
 id), the camera inside spheres, extreme radii, and material corner cases (roughness 0 and 1, IOR 1, metallic +
 transmission, strong emitters, black and over-range base colours).  Bit-exact, like every other parity test."""
+import os
+
 import numpy as np
 import pytest
 
@@ -40,7 +42,8 @@ def random_scene(dxrs, rng, n):
     return s, m
 
 
-@pytest.mark.parametrize("seed", range(96))
+# PT_FUZZ_SEEDS=N widens the sweep for a soak run (the default 96 keeps the suite short)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_SEEDS", "96"))))
 def test_random_scene_matches_oracle(dxrs, host, oracle, renderer, seed):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 200]))
@@ -61,3 +64,24 @@ def test_random_scene_matches_oracle(dxrs, host, oracle, renderer, seed):
     assert st.rays == ost.rays
     assert count_mismatch(img, ref) == 0
     assert np.isfinite(img).all()
+
+
+# scenes too large for the LDS-resident path: global-memory BVH, split traverse/shade schedule
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_LARGE_SEEDS", "12"))))
+def test_random_large_scene_matches_oracle(dxrs, host, oracle, renderer, seed):
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([450, 1000, 4000]))
+    spheres, materials = random_scene(dxrs, rng, n)
+    sd = host.scene(dxrs.host.SCENE_SMALL)[2]
+    w, h = int(rng.choice([96, 129])), int(rng.choice([64, 75]))
+    bounces, spp = int(rng.choice([1, 4, 8])), int(rng.choice([1, 3]))
+    pos = (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), -12.0) if seed % 4 else (0.1, 0.2, 0.3)
+    cam = host.camera(w, h, position=pos, look_at=(0.0, 0.0, 0.0) if seed % 2 else None, jitter_index=seed)
+    gs = dxrs.types.graphics_settings(w, h, frame_index=seed * 104729, bounces=bounces, spp=spp, rr=bool(seed % 3))
+    renderer.set_scene(spheres, materials, sd)
+    renderer.set_camera(cam)
+    renderer.set_constants(gs)
+    img, st = renderer.render()
+    ref, ost = oracle.render(spheres, materials, sd, cam, gs, threads=8)
+    assert st.rays == ost.rays
+    assert count_mismatch(img, ref) == 0
