@@ -7,8 +7,10 @@
 
 A "step" is one frame: BASELINE.json configs[1] = demo default sphere scene (seed 0), 1920x1080, 1 spp, 8 bounces,
 Russian roulette on, sky-gradient environment, FrameIndex = step, camera jitter = Halton2D(step % 8 + 1) - 0.5.
-With N > 1 the frame is tile-partitioned (32x32 tiles, tile t -> rank t % N), every rank renders its tiles, the HDR
-tiles are gathered to rank 0 over RCCL and un-swizzled there (strong scaling: the frame is fixed).
+With N > 1 the frame is tile-partitioned (32x32 tiles, interleaved; rank 0, which assembles the frame, carries a larger,
+auto-tuned share because its tiles need no transfer), every rank renders its tiles, the HDR tiles are gathered to rank 0
+over RCCL -- one collective per batch of frames in flight -- and un-swizzled there (strong scaling: the frame is fixed).
+See directx-raytracing-spheres-demo_amd/exchange.py.
 Inputs (scene, BVH) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -41,6 +43,10 @@ def main():
     ap.add_argument("--animate", action="store_true",
                     help="demo scene in motion (closed-form springs + Moon orbit, 1/60 s per frame): per-frame sphere upload + LBVH refit inside the timed region")
     ap.add_argument("--force-tiles", action="store_true", help="run the tile / gather / un-swizzle path even with one rank (rehearsal of the N > 1 path)")
+    ap.add_argument("--root-weight", type=int, default=-1,
+                    help="tiled path: shares of the frame rank 0 renders (every other rank renders one; 0 = rank 0 renders everything); "
+                         "-1 = measure a few candidates before the warm-up and keep the fastest")
+    ap.add_argument("--gather-batch", type=int, default=0, help="tiled path: frames per RCCL gather (0 = frames in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="the CPU baseline renders every n-th row of each frame")
@@ -82,24 +88,28 @@ def main():
     nbuf = args.frames_in_flight
     r = dxrs_amd.Renderer(device=local_rank, stream=stream, frames_in_flight=nbuf)
     accel = r.set_scene(spheres, materials, sd)
-    r.set_partition(rank, world)
     gs = graphics_settings(w, h, frame_index=0, bounces=args.bounces, spp=args.spp)
     r.set_constants(gs)
-    ts = 32
+    cams = [host.camera(w, h, jitter_index=k, jitter_count=8) for k in range(8)]
+
+    def set_frame(k, rr=None):
+        rr = rr or r
+        gs.FrameIndex = k
+        if args.animate:
+            rr.update_spheres(anim[k])  # upload + LBVH refit on this frame's stream (Scene::Refresh + TLAS rebuild analogue)
+        rr.set_camera(cams[k % 8])
+        rr.set_constants(gs)
+
     # multi-buffered outputs: frame k writes buffer k % frames_in_flight (the reference's swap chain, generalised)
+    tune_log = {}
     if not tiled:
         frames = [torch.empty((h * w, 4), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-        frame = frames[0]
     else:
-        max_tiles = r.tiles_count(0)
-        packeds = [torch.zeros((max_tiles * ts * ts, 4), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-        packed = packeds[0]
-        if rank == 0:
-            gathered = torch.empty((world, max_tiles * ts * ts, 4), dtype=torch.float32, device=dev)
-            gather_list = list(gathered.unbind(0))
-            frame = torch.empty((h * w, 4), dtype=torch.float32, device=dev)
-
-    cams = [host.camera(w, h, jitter_index=k, jitter_count=8) for k in range(8)]
+        from dxrs_amd.exchange import HipOps, TileExchange
+        # the batch must cover the frames in flight: a batch buffer is reused two batches later, and a frame only waits for
+        # the caller-stream marker frames_in_flight - 1 calls back (see pt_api.hip render_common)
+        batch = max(args.gather_batch or nbuf, nbuf - 1, 1)
+        ex = TileExchange(HipOps(r, dev, set_frame), w, h, rank, world, batch, rehearse=args.force_tiles and world == 1)
     if args.animate:
         if args.scene != "demo":
             raise SystemExit("--animate is defined for the demo scene")
@@ -107,28 +117,19 @@ def main():
         anim = [host.scene_at_time(0, k / 60.0) for k in range(n_anim)]  # host-side Tick (MyScene::SetTime), precomputed
 
     def step(k):
-        gs.FrameIndex = k
-        if args.animate:
-            r.update_spheres(anim[k])  # upload + LBVH refit on this frame's stream (Scene::Refresh + TLAS rebuild analogue)
-        r.set_camera(cams[k % 8])
-        r.set_constants(gs)
         if not tiled:
+            set_frame(k)
             r.render_device(frames[k % nbuf].data_ptr())
         else:
-            r.render_tiles(packeds[k % nbuf].data_ptr())
-            dist.gather(packeds[k % nbuf], gather_list if rank == 0 else None, dst=0)
-            if rank == 0:
-                r.unpack_tiles(gathered.data_ptr(), max_tiles, frame.data_ptr())
+            ex.submit(k)  # render this rank's tiles; every `batch` frames: one RCCL gather + un-swizzle on rank 0
 
     def step_on(rr, k):
         """one frame on renderer rr (this rank's share, no gather): used for the exclusive-kernel measurement"""
-        gs.FrameIndex = k
-        rr.set_camera(cams[k % 8])
-        rr.set_constants(gs)
+        set_frame(k, rr)
         if not tiled:
             rr.render_device(frames[0].data_ptr())
-        else:
-            rr.render_tiles(packeds[0].data_ptr())
+        elif ex.own_px:
+            rr.render_tiles(ex.own[0][0].data_ptr())
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -136,18 +137,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for k in range(args.warmup):
-        step(k)
-    r.totals(reset=True)
-    sync_all()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    torch.cuda.synchronize(dev)
-    if tiled:
-        dist.barrier()
+    def run_steps(first, n):
+        """n frames, fully drained: barrier + synchronize on both sides; returns seconds"""
+        sync_all()
+        t = time.perf_counter()
+        for k in range(n):
+            step(first + k)
+        if tiled:
+            ex.finish()  # flush a partial last batch
         torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+        if tiled:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        return time.perf_counter() - t
+
+    if tiled and world > 1:
+        if args.root_weight >= 0:
+            ex.configure(args.root_weight)
+        else:
+            # untimed, before the warm-up: try a few root weights on the live job and keep the fastest
+            n_tune = 6 * ex.batch
+            ex.autotune(lambda e: run_steps(0, n_tune), sync_all, log=tune_log)
+    run_steps(0, args.warmup)
+    r.totals(reset=True)
+    elapsed = run_steps(args.warmup, args.steps)
     tot = r.totals(reset=True)
     queue_sizes = r.queue_sizes() if args.spp == 1 else []
     # Second timed region, identical except that a HIP event pair brackets every kernel launch on the stream it runs on:
@@ -156,15 +169,7 @@ def main():
     prof, elapsed_ev = None, None
     if not args.no_roofline:
         r.set_profiling(True)
-        sync_all()
-        t1 = time.perf_counter()
-        for k in range(args.steps):
-            step(args.warmup + args.steps + k)
-        torch.cuda.synchronize(dev)
-        if tiled:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-        elapsed_ev = time.perf_counter() - t1
+        elapsed_ev = run_steps(args.warmup + args.steps, args.steps)
         prof = r.profile(reset=True)
         r.set_profiling(False)
         tot_ev = r.totals(reset=True)
@@ -198,6 +203,8 @@ def main():
             "config": {
                 "workload": f"{args.scene} sphere scene (seed {1 if args.scene == 'procedural' else 0}, {len(spheres)} spheres), {w}x{h}, {args.spp} spp, {args.bounces} bounces, RR on, sky env"
                             + (f", 32x32 tiles interleaved over {world} GPU(s) + RCCL gather to rank 0" if tiled else ""),
+                **({"tile_exchange": {"root_weight": ex.root_weight, "frames_per_gather": ex.batch, "root_tiles": ex.n_root,
+                                      "tiles_per_other_rank": ex.n_other, "autotune": tune_log or None}} if tiled else {}),
                 "frames_in_flight": args.frames_in_flight,
                 "animated": bool(args.animate),
                 "rays_per_frame": rays / args.steps,
@@ -243,7 +250,9 @@ def main():
         excl = None
         if args.frames_in_flight > 1 and not split:
             r1 = dxrs_amd.Renderer(device=local_rank, stream=stream, frames_in_flight=1)
-            r1.set_scene(spheres, materials, sd); r1.set_partition(rank, world); r1.set_constants(gs)
+            r1.set_scene(spheres, materials, sd); r1.set_constants(gs)
+            if tiled:
+                r1.set_partition_ex(*ex.range)
             for k in range(3):
                 step_on(r1, k)
             r1.set_profiling(True)

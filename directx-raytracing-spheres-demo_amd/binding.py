@@ -16,7 +16,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR
 # every symbol include/pt_api.h declares
 API_SYMBOLS = [
     "pt_create", "pt_destroy", "pt_set_scene", "pt_build_accel", "pt_update_spheres", "pt_refit_accel", "pt_set_camera", "pt_set_constants", "pt_render",
-    "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_trace_rays", "pt_trace_rays_stats", "pt_accel_download",
+    "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_set_partition_ex", "pt_tiles_count_ex", "pt_unpack_tiles_ex", "pt_trace_rays", "pt_trace_rays_stats", "pt_accel_download",
     "pt_accel_download_order", "pt_lbvh_build_host", "pt_set_profiling", "pt_get_profile", "pt_get_totals", "pt_get_queue_sizes", "pt_synchronize", "pt_last_error", "pt_version",
 ]
 
@@ -64,6 +64,12 @@ class HipLib:
         lib.pt_render_tiles.argtypes = [vp, vp, C.POINTER(PtStats)]
         lib.pt_unpack_tiles.restype = C.c_int
         lib.pt_unpack_tiles.argtypes = [vp, vp, u32, vp]
+        lib.pt_set_partition_ex.restype = C.c_int
+        lib.pt_set_partition_ex.argtypes = [vp, u32, u32, u32]
+        lib.pt_tiles_count_ex.restype = u32
+        lib.pt_tiles_count_ex.argtypes = [vp, u32, u32, u32]
+        lib.pt_unpack_tiles_ex.restype = C.c_int
+        lib.pt_unpack_tiles_ex.argtypes = [vp, vp, C.c_uint64, u32, u32, u32, u32, vp]
         lib.pt_trace_rays.restype = C.c_int
         lib.pt_trace_rays.argtypes = [vp, vp, vp, u32, C.c_float, C.c_int, vp, vp]
         lib.pt_trace_rays_stats.restype = C.c_int
@@ -187,6 +193,13 @@ class Renderer:
     def tiles_count(self, rank):
         return int(self._lib.pt_tiles_count(self._ctx, rank))
 
+    def set_partition_ex(self, first, run, stride):
+        """own the tiles t with first <= t % stride < first + run (weighted partition; see include/pt_api.h)"""
+        self._check(self._lib.pt_set_partition_ex(self._ctx, first, run, stride))
+
+    def tiles_count_ex(self, first, run, stride):
+        return int(self._lib.pt_tiles_count_ex(self._ctx, first, run, stride))
+
     def set_profiling(self, enabled):
         self._check(self._lib.pt_set_profiling(self._ctx, 1 if enabled else 0))
 
@@ -236,6 +249,9 @@ class Renderer:
 
     def unpack_tiles(self, gathered_ptr, max_tiles_per_rank, frame_ptr):
         self._check(self._lib.pt_unpack_tiles(self._ctx, C.c_void_p(gathered_ptr), max_tiles_per_rank, C.c_void_p(frame_ptr)))
+
+    def unpack_tiles_ex(self, packed_ptr, part_stride_px, n_parts, first0, run, stride, frame_ptr):
+        self._check(self._lib.pt_unpack_tiles_ex(self._ctx, C.c_void_p(packed_ptr), part_stride_px, n_parts, first0, run, stride, C.c_void_p(frame_ptr)))
 
     def trace_rays(self, origins, directions, tmin=0.0, use_bvh=True):
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)

@@ -46,7 +46,8 @@ struct Lane {
     uint32_t* h_counts = nullptr;  // pinned
     // queue sizes of a recent frame (pinned, written by an async copy, read without waiting): they only size the
     // launch grids -- every kernel is a grid-stride loop, so a stale or missing estimate costs time, never correctness
-    uint32_t* h_prev_counts = nullptr;
+    uint32_t* h_prev_counts = nullptr;   // host-mapped: the GPU writes it when it folds a frame's counters (no copy call)
+    uint32_t* d_prev_counts = nullptr;   // device address of h_prev_counts
     uint64_t prev_signature = 0;
     unsigned long long* d_totals = nullptr;  // [0] running secondary-ray total, [1] last folded frame, [2],[3] tail counters
     // private copy of the moving part of the scene (pt_update_spheres / pt_refit_accel): spheres, Morton-ordered spheres
@@ -95,7 +96,8 @@ struct PtContext {
     PtCamera cam{};
     PtGraphicsSettings gs{};
     bool cam_set = false, gs_set = false;
-    uint32_t rank = 0, world = 1;
+    uint32_t rank = 0, world = 1;                       // pt_set_partition (kept for pt_tiles_count(rank))
+    uint32_t part_first = 0, part_run = 1, part_stride = 1;  // the residue range this context renders (pt_set_partition_ex)
 
     // work buffers: one set per frame in flight.  Frame f runs on lane f % n_lanes, on that lane's own stream, so the
     // latency-bound looping pass of one frame overlaps the throughput-bound first passes of the next.
@@ -177,8 +179,9 @@ PtStatus ensure_buffers(PtContext* c, Lane& L, size_t n_slots, bool need_spp, bo
         free_dev(L.d_counts);
         if (L.h_counts) { (void)hipHostFree(L.h_counts); L.h_counts = nullptr; }
         if (L.h_prev_counts) { (void)hipHostFree(L.h_prev_counts); L.h_prev_counts = nullptr; }
-        PT_HIP(c, hipHostMalloc(&L.h_prev_counts, n_counts * sizeof(uint32_t)));
+        PT_HIP(c, hipHostMalloc(&L.h_prev_counts, n_counts * sizeof(uint32_t), hipHostMallocMapped));
         std::memset(L.h_prev_counts, 0, n_counts * sizeof(uint32_t));
+        PT_HIP(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&L.d_prev_counts), L.h_prev_counts, 0));
         L.prev_signature = 0;
         PT_HIP(c, hipMalloc(&L.d_counts, 4 * n_counts * sizeof(uint32_t)));  // 2 parities x (queue sizes + work cursors)
         PT_HIP(c, hipMemsetAsync(L.d_counts, 0, 4 * n_counts * sizeof(uint32_t), L.stream));
@@ -276,16 +279,18 @@ FrameCounters make_counters(const Lane& L, uint32_t parity)
     fc.tail_rays = L.d_totals + 2 + parity;
     fc.fold_tail = L.d_totals + 2 + (parity ^ 1u);
     fc.totals = L.d_totals;
+    fc.host_counts = L.d_prev_counts;
     return fc;
 }
 
-// fold both parities of a lane into its totals (leaves all per-frame counters zero)
+// fold both parities of a lane into its totals (leaves all per-frame counters zero): the older frame first, so that the
+// host-mapped queue sizes end up describing the lane's latest frame (counters that were already folded publish nothing)
 hipError_t flush_all_counters(Lane& L)
 {
     if (!L.d_counts) return hipSuccess;
-    for (uint32_t p = 0; p < 2; p++) {
-        const FrameCounters fc = make_counters(L, p);
-        hipError_t e = launch_flush_counters(fc.counts, fc.n_counts, fc.tail_rays, fc.totals, L.stream);
+    for (uint32_t i = 0; i < 2; i++) {
+        const FrameCounters fc = make_counters(L, L.parity ^ 1u ^ i);
+        hipError_t e = launch_flush_counters(fc.counts, fc.n_counts, fc.tail_rays, fc.totals, fc.host_counts, L.stream);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -340,7 +345,13 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         // completion waits were queued on the caller's stream after that marker.
         const uint64_t nl = c->n_lanes;
         PT_HIP(c, hipEventRecord(c->ev_in[c->calls % nl], c->stream));
-        PT_HIP(c, hipStreamWaitEvent(L.stream, c->ev_in[c->calls >= nl - 1 ? (c->calls - (nl - 1)) % nl : 0], 0));
+        // (a stream wait costs the host ~8 us, a query ~1: when the GPU is ahead of the host -- small frames -- the marker has
+        // usually completed already and the wait is skipped)
+        const hipEvent_t marker = c->ev_in[c->calls >= nl - 1 ? (c->calls - (nl - 1)) % nl : 0];
+        if (hipEventQuery(marker) != hipSuccess) {
+            (void)hipGetLastError();  // hipErrorNotReady is not an error here
+            PT_HIP(c, hipStreamWaitEvent(L.stream, marker, 0));
+        }
         c->calls++;
     }
 
@@ -459,11 +470,8 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
             }
         }
     }
-    if (spp == 1) {
-        // remember this frame's queue sizes for the next frame's grid sizing (no wait: see h_prev_counts)
-        PT_HIP(c, hipMemcpyAsync(L.h_prev_counts, counts, L.cap_counts * sizeof(uint32_t), hipMemcpyDeviceToHost, L.stream));
-        L.prev_signature = signature;
-    }
+    // this frame's queue sizes reach h_prev_counts when the lane's next frame folds them (frame_counters_begin): no copy call
+    if (spp == 1) L.prev_signature = signature;
     if (L.stream != c->stream) {
         // whatever the caller queues next on its stream (a gather, a copy, the next use of `out`) sees the finished frame
         PT_HIP(c, hipEventRecord(L.ev_done, L.stream));
@@ -487,8 +495,8 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         // totals[1] is this frame's secondary-ray count
         {
             const FrameCounters other = make_counters(L, L.parity ^ 1u);
-            PT_HIP(c, launch_flush_counters(other.counts, other.n_counts, other.tail_rays, other.totals, L.stream));
-            PT_HIP(c, launch_flush_counters(fc.counts, fc.n_counts, fc.tail_rays, fc.totals, L.stream));
+            PT_HIP(c, launch_flush_counters(other.counts, other.n_counts, other.tail_rays, other.totals, other.host_counts, L.stream));
+            PT_HIP(c, launch_flush_counters(fc.counts, fc.n_counts, fc.tail_rays, fc.totals, fc.host_counts, L.stream));
         }
         unsigned long long secondary = 0;
         PT_HIP(c, hipMemcpyAsync(&secondary, L.d_totals + 1, sizeof secondary, hipMemcpyDeviceToHost, L.stream));
@@ -506,15 +514,29 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     return PT_OK;
 }
 
-uint64_t count_tile_pixels(uint32_t w, uint32_t h, uint32_t ts, uint32_t rank, uint32_t world)
+// tiles t in [0, total) with first <= t % stride < first + run
+uint32_t count_tiles(uint32_t total, uint32_t first, uint32_t run, uint32_t stride)
+{
+    const uint32_t rem = total % stride;
+    return (total / stride) * run + (rem > first ? std::min(rem - first, run) : 0u);
+}
+
+uint64_t count_tile_pixels(uint32_t w, uint32_t h, uint32_t ts, uint32_t first, uint32_t run, uint32_t stride)
 {
     const uint32_t tx = (w + ts - 1) / ts, ty = (h + ts - 1) / ts, total = tx * ty;
     uint64_t px = 0;
-    for (uint32_t t = rank; t < total; t += world) {
-        const uint32_t x0 = (t % tx) * ts, y0 = (t / tx) * ts;
-        px += (uint64_t)std::min(ts, w - x0) * std::min(ts, h - y0);
-    }
+    for (uint32_t base = 0; base < total; base += stride)
+        for (uint32_t t = base + first; t < std::min(base + first + run, total); t++) {
+            const uint32_t x0 = (t % tx) * ts, y0 = (t / tx) * ts;
+            px += (uint64_t)std::min(ts, w - x0) * std::min(ts, h - y0);
+        }
     return px;
+}
+
+uint32_t frame_tiles(const PtContext* c)
+{
+    const uint32_t ts = c->tile_size;
+    return ((c->gs.RenderSize[0] + ts - 1) / ts) * ((c->gs.RenderSize[1] + ts - 1) / ts);
 }
 
 }  // namespace
@@ -767,15 +789,29 @@ PtStatus pt_set_partition(PtContext* c, uint32_t rank, uint32_t world)
     if (world == 0 || rank >= world) return fail(c, PT_ERR_INVALID_ARG, "pt_set_partition: need rank < world");
     c->rank = rank;
     c->world = world;
+    c->part_first = rank; c->part_run = 1; c->part_stride = world;
+    return PT_OK;
+}
+
+PtStatus pt_set_partition_ex(PtContext* c, uint32_t first, uint32_t run, uint32_t stride)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (stride == 0 || (uint64_t)first + run > stride) return fail(c, PT_ERR_INVALID_ARG, "pt_set_partition_ex: need first + run <= stride, stride > 0");
+    c->part_first = first; c->part_run = run; c->part_stride = stride;
+    c->rank = 0; c->world = 1;  // pt_tiles_count(rank) / pt_unpack_tiles describe the plain interleave only
     return PT_OK;
 }
 
 uint32_t pt_tiles_count(PtContext* c, uint32_t rank)
 {
     if (!c || !c->gs_set || rank >= c->world) return 0;
-    const uint32_t ts = c->tile_size;
-    const uint32_t total = ((c->gs.RenderSize[0] + ts - 1) / ts) * ((c->gs.RenderSize[1] + ts - 1) / ts);
-    return rank < total ? (total - rank + c->world - 1) / c->world : 0;
+    return count_tiles(frame_tiles(c), rank, 1, c->world);
+}
+
+uint32_t pt_tiles_count_ex(PtContext* c, uint32_t first, uint32_t run, uint32_t stride)
+{
+    if (!c || !c->gs_set || stride == 0 || (uint64_t)first + run > stride) return 0;
+    return count_tiles(frame_tiles(c), first, run, stride);
 }
 
 PtStatus pt_render(PtContext* c, const PtRect* rect, void* out, int out_is_device, PtStats* stats)
@@ -834,15 +870,17 @@ PtStatus pt_render_tiles(PtContext* c, void* out_device_packed, PtStats* stats)
     pm.tiles_x = (w + ts - 1) / ts;
     pm.inv_tiles_x = 1.0f / (float)pm.tiles_x;
     pm.tiles_total = pm.tiles_x * ((h + ts - 1) / ts);
-    pm.rank = c->rank; pm.world = c->world;
-    const uint64_t slots = (uint64_t)pt_tiles_count(c, c->rank) * ts * ts;
+    pm.first = c->part_first; pm.run = c->part_run; pm.stride = c->part_stride;
+    pm.inv_run = pm.run ? 1.0f / (float)pm.run : 0.0f;
+    const uint64_t slots = (uint64_t)count_tiles(pm.tiles_total, pm.first, pm.run, pm.stride) * ts * ts;
     if (slots == 0) {  // this rank owns no tile of the frame
         if (stats) std::memset(stats, 0, sizeof *stats);
         return PT_OK;
     }
     if (slots > 0xFFFFFFFFull) return fail(c, PT_ERR_INVALID_ARG, "pt_render_tiles: too many pixels");
     pm.n_slots = (uint32_t)slots;
-    return render_common(c, pm, count_tile_pixels(w, h, ts, c->rank, c->world), static_cast<float4*>(out_device_packed), stats);
+    pm.exact_div = (slots >> (2u * pm.ts_shift)) >= (1ull << 22) ? 1u : 0u;
+    return render_common(c, pm, count_tile_pixels(w, h, ts, pm.first, pm.run, pm.stride), static_cast<float4*>(out_device_packed), stats);
 }
 
 PtStatus pt_unpack_tiles(PtContext* c, const void* gathered, uint32_t max_tiles_per_rank, void* frame)
@@ -852,8 +890,25 @@ PtStatus pt_unpack_tiles(PtContext* c, const void* gathered, uint32_t max_tiles_
     if (max_tiles_per_rank < pt_tiles_count(c, 0)) return fail(c, PT_ERR_INVALID_ARG, "pt_unpack_tiles: max_tiles_per_rank too small");
     PT_HIP(c, hipSetDevice(c->device));
     const uint32_t ts = c->tile_size, w = c->gs.RenderSize[0], h = c->gs.RenderSize[1];
-    PT_HIP(c, launch_unpack_tiles(static_cast<const float4*>(gathered), static_cast<float4*>(frame), w, h, ts, (w + ts - 1) / ts, c->world,
-                                  max_tiles_per_rank, c->stream));
+    PT_HIP(c, launch_unpack_tiles(static_cast<const float4*>(gathered), static_cast<float4*>(frame), w, h, ts, (w + ts - 1) / ts, 0, 1, c->world,
+                                  c->world, (uint64_t)max_tiles_per_rank * ts * ts, c->stream));
+    return PT_OK;
+}
+
+PtStatus pt_unpack_tiles_ex(PtContext* c, const void* packed, uint64_t part_stride_px, uint32_t n_parts, uint32_t first0, uint32_t run,
+                            uint32_t stride, void* frame)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!packed || !frame || !c->gs_set) return fail(c, PT_ERR_INVALID_ARG, "pt_unpack_tiles_ex: null pointer or no constants");
+    if (stride == 0 || run == 0 || n_parts == 0 || (uint64_t)first0 + (uint64_t)n_parts * run > stride)
+        return fail(c, PT_ERR_INVALID_ARG, "pt_unpack_tiles_ex: need run, n_parts > 0 and first0 + n_parts * run <= stride");
+    const uint32_t ts = c->tile_size, w = c->gs.RenderSize[0], h = c->gs.RenderSize[1];
+    // the first part owns at least as many tiles as any later one
+    if (n_parts > 1 && part_stride_px < (uint64_t)count_tiles(frame_tiles(c), first0, run, stride) * ts * ts)
+        return fail(c, PT_ERR_INVALID_ARG, "pt_unpack_tiles_ex: part_stride_px smaller than one part's tiles");
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, launch_unpack_tiles(static_cast<const float4*>(packed), static_cast<float4*>(frame), w, h, ts, (w + ts - 1) / ts, first0, run, stride,
+                                  n_parts, part_stride_px, c->stream));
     return PT_OK;
 }
 
@@ -978,8 +1033,11 @@ PtStatus pt_get_queue_sizes(PtContext* c, uint32_t* sizes, uint32_t capacity, ui
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, sync_all(c));
     *n = 0;
-    const Lane& L = c->lanes[c->last_lane];
+    Lane& L = c->lanes[c->last_lane];
     if (!L.h_prev_counts || !L.prev_signature) return PT_OK;
+    // the latest frame's sizes are published when its counters are folded: do that now if no later frame has
+    PT_HIP(c, flush_all_counters(L));
+    PT_HIP(c, hipStreamSynchronize(L.stream));
     uint32_t k = 0;
     for (; k < L.cap_counts && k < capacity; k++) {
         sizes[k] = L.h_prev_counts[k];

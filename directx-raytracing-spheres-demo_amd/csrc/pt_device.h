@@ -52,10 +52,13 @@ struct PixelMap {
     uint32_t img_w, img_h;        // RenderSize
     uint32_t rx, ry, rw, rh;      // rect (mode 0)
     uint32_t blocks_x;            // ceil(rw / 8) (mode 0)
-    uint32_t ts, tiles_x, tiles_total, rank, world;  // mode 1 (ts = 1 << ts_shift)
+    uint32_t ts, tiles_x, tiles_total;  // mode 1 (ts = 1 << ts_shift)
+    // mode 1 ownership: the tiles t with first <= t % stride < first + run, in increasing t (pt_set_partition_ex);
+    // the plain rank/world interleave is (first, run, stride) = (rank, 1, world)
+    uint32_t first, run, stride;
     uint32_t ts_shift;
     uint32_t n_slots;
-    float inv_blocks_x, inv_tiles_x;  // reciprocals for fast_div
+    float inv_blocks_x, inv_tiles_x, inv_run;  // reciprocals for fast_div
     uint32_t exact_div;               // 1: slot counts too large for the float-reciprocal division
 };
 
@@ -95,7 +98,13 @@ __device__ __forceinline__ PixelRef slot_to_pixel(const PixelMap& m, uint32_t sl
         const uint32_t bpt_shift = m.ts_shift - 3u;  // 8x8 blocks per tile row = ts / 8
         const uint32_t b = w >> 6, l = w & 63u;
         const uint32_t lx = ((b & ((1u << bpt_shift) - 1u)) << 3) + (l & 7u), ly = ((b >> bpt_shift) << 3) + (l >> 3);
-        const uint32_t gt = m.rank + k * m.world;
+        uint32_t gt;
+        if (m.run == 1u) {
+            gt = m.first + k * m.stride;
+        } else {
+            const uint32_t q = fast_div(k, m.run, m.inv_run, m.exact_div != 0);
+            gt = m.first + q * m.stride + (k - q * m.run);
+        }
         const uint32_t ty = fast_div(gt, m.tiles_x, m.inv_tiles_x, m.exact_div != 0), tx = gt - ty * m.tiles_x;
         r.px = (tx << m.ts_shift) + lx;
         r.py = (ty << m.ts_shift) + ly;
@@ -126,6 +135,8 @@ struct FrameCounters {
     unsigned long long* tail_rays;
     unsigned long long* fold_tail;
     unsigned long long* totals;
+    uint32_t* host_counts;  // host-mapped (pinned) copy of the queue sizes of the frame being folded: launch-grid estimates
+                            // for later frames reach the host without a copy call; may be null
 };
 
 // per-slot scratch (only touched when needed, see shade kernel)

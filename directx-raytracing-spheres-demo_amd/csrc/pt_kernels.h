@@ -26,11 +26,12 @@ hipError_t launch_trace(const SceneView& sv, const float* o, const float* d, uin
                         uint32_t* out_id, uint2* out_visits, hipStream_t stream);
 hipError_t launch_tail(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const Scratch& scratch, float4* out,
                        const uint32_t* count_ptr, unsigned long long* tail_rays, uint32_t grid, hipStream_t stream);
-hipError_t launch_flush_counters(uint32_t* counts, uint32_t n_counts, unsigned long long* tail, unsigned long long* totals, hipStream_t stream);
+hipError_t launch_flush_counters(uint32_t* counts, uint32_t n_counts, unsigned long long* tail, unsigned long long* totals, uint32_t* host_counts,
+                                 hipStream_t stream);
 hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const RayQueue& qout,
                          const Scratch& scratch, float4* out, const uint32_t* count_in, uint32_t* count_out, const FrameCounters& fc,
                          bool primary, bool loop, uint32_t threads, uint32_t grid, hipStream_t stream);
-hipError_t launch_unpack_tiles(const float4* gathered, float4* frame, uint32_t w, uint32_t h, uint32_t ts, uint32_t tiles_x, uint32_t world,
-                               uint32_t max_tiles, hipStream_t stream);
+hipError_t launch_unpack_tiles(const float4* packed, float4* frame, uint32_t w, uint32_t h, uint32_t ts, uint32_t tiles_x, uint32_t first0,
+                               uint32_t run, uint32_t stride, uint32_t n_parts, uint64_t part_stride, hipStream_t stream);
 
 }  // namespace pt

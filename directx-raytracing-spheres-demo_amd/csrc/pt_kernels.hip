@@ -36,7 +36,7 @@ __device__ __forceinline__ float slab_rcp(float d)
 // Called by every thread of ONE block: fold a finished frame's counters (queue sizes 1..n + its tail counter) into
 // the running totals and leave them zeroed.
 __device__ __forceinline__ void fold_counters(uint32_t* __restrict__ counts, uint32_t n_counts, unsigned long long* __restrict__ tail,
-                                              unsigned long long* __restrict__ totals)
+                                              unsigned long long* __restrict__ totals, uint32_t* __restrict__ host_counts)
 {
     __shared__ unsigned long long s_sum[16];
     unsigned long long s = 0;
@@ -53,6 +53,10 @@ __device__ __forceinline__ void fold_counters(uint32_t* __restrict__ counts, uin
         *tail = 0ull;
     }
     __syncthreads();
+    // publish the folded frame's queue sizes to the host (it sizes later frames' grids from them); counts[0] == 0 means
+    // these counters hold no frame (already folded)
+    if (host_counts && counts[0] != 0u)
+        for (uint32_t k = threadIdx.x; k <= n_counts; k += blockDim.x) host_counts[k] = counts[k];
     for (uint32_t k = threadIdx.x; k < 2u * (n_counts + 1u); k += blockDim.x) counts[k] = 0u;  // queue sizes + work cursors
 }
 
@@ -60,7 +64,7 @@ __device__ __forceinline__ void fold_counters(uint32_t* __restrict__ counts, uin
 // This frame's counters were zeroed when the frame before the previous one was folded (or at allocation).
 __device__ __forceinline__ void frame_counters_begin(const FrameCounters& fc, uint32_t n_slots)
 {
-    fold_counters(fc.fold_counts, fc.n_counts, fc.fold_tail, fc.totals);
+    fold_counters(fc.fold_counts, fc.n_counts, fc.fold_tail, fc.totals, fc.host_counts);
     if (threadIdx.x == 0) fc.counts[0] = n_slots;
 }
 
@@ -725,24 +729,31 @@ __global__ void brute_kernel(SceneView sv, const float* __restrict__ o, const fl
     }
 }
 
-// Tile un-swizzle after the gather: gathered = [rank][max_tiles][ts*ts] float4 -> frame W*H float4.
-__global__ void unpack_tiles_kernel(const float4* __restrict__ gathered, float4* __restrict__ frame, uint32_t w, uint32_t h, uint32_t ts,
-                                    uint32_t tiles_x, uint32_t world, uint32_t max_tiles)
+// Tile un-swizzle after the exchange: packed = [part][tiles][ts*ts] float4 -> frame W*H float4, where part i
+// holds, in increasing tile order, the tiles t with first0 + i*run <= t % stride < first0 + (i+1)*run; consecutive parts
+// are part_stride float4 apart.  Pixels of tiles owned by none of the n_parts parts are left untouched (another call
+// with the other parts fills them).
+__global__ void unpack_tiles_kernel(const float4* __restrict__ packed, float4* __restrict__ frame, uint32_t w, uint32_t h, uint32_t ts,
+                                    uint32_t tiles_x, uint32_t first0, uint32_t run, uint32_t stride, uint32_t n_parts, uint64_t part_stride)
 {
     const uint32_t n = w * h;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
         const uint32_t x = p % w, y = p / w;
         const uint32_t gt = (y / ts) * tiles_x + (x / ts);
-        const uint32_t rank = gt % world, k = gt / world;
-        frame[p] = gathered[((size_t)rank * max_tiles + k) * ts * ts + (y % ts) * ts + (x % ts)];
+        const uint32_t period = gt / stride, res = gt - period * stride;
+        if (res < first0) continue;
+        const uint32_t d = res - first0, part = d / run;
+        if (part >= n_parts) continue;
+        const uint32_t k = period * run + (d - part * run);
+        frame[p] = packed[(size_t)part * part_stride + (size_t)k * ts * ts + (y % ts) * ts + (x % ts)];
     }
 }
 
 // totals[0] += sum of counts[1..n_iters] (secondary rays of this frame); one thread
 // Fold one parity's counters into the running total (pt_get_totals / stats); leaves them zeroed.
-__global__ void flush_counters_kernel(uint32_t* counts, uint32_t n_counts, unsigned long long* tail, unsigned long long* totals)
+__global__ void flush_counters_kernel(uint32_t* counts, uint32_t n_counts, unsigned long long* tail, unsigned long long* totals, uint32_t* host_counts)
 {
-    if (blockIdx.x == 0) fold_counters(counts, n_counts, tail, totals);
+    if (blockIdx.x == 0) fold_counters(counts, n_counts, tail, totals, host_counts);
 }
 
 // ------------------------------------------------------------------------------------------------ launch wrappers
@@ -861,18 +872,20 @@ hipError_t launch_trace(const SceneView& sv, const float* o, const float* d, uin
     return hipGetLastError();
 }
 
-hipError_t launch_flush_counters(uint32_t* counts, uint32_t n_counts, unsigned long long* tail, unsigned long long* totals, hipStream_t stream)
+hipError_t launch_flush_counters(uint32_t* counts, uint32_t n_counts, unsigned long long* tail, unsigned long long* totals, uint32_t* host_counts,
+                                 hipStream_t stream)
 {
-    hipLaunchKernelGGL(flush_counters_kernel, dim3(1), dim3(256), 0, stream, counts, n_counts, tail, totals);
+    hipLaunchKernelGGL(flush_counters_kernel, dim3(1), dim3(256), 0, stream, counts, n_counts, tail, totals, host_counts);
     return hipGetLastError();
 }
 
-hipError_t launch_unpack_tiles(const float4* gathered, float4* frame, uint32_t w, uint32_t h, uint32_t ts, uint32_t tiles_x, uint32_t world,
-                               uint32_t max_tiles, hipStream_t stream)
+hipError_t launch_unpack_tiles(const float4* packed, float4* frame, uint32_t w, uint32_t h, uint32_t ts, uint32_t tiles_x, uint32_t first0,
+                               uint32_t run, uint32_t stride, uint32_t n_parts, uint64_t part_stride,
+                               hipStream_t stream)
 {
     const uint32_t n = w * h;
     const uint32_t grid = (n + 255u) / 256u < 4096u ? (n + 255u) / 256u : 4096u;
-    hipLaunchKernelGGL(unpack_tiles_kernel, dim3(grid), dim3(256), 0, stream, gathered, frame, w, h, ts, tiles_x, world, max_tiles);
+    hipLaunchKernelGGL(unpack_tiles_kernel, dim3(grid), dim3(256), 0, stream, packed, frame, w, h, ts, tiles_x, first0, run, stride, n_parts, part_stride);
     return hipGetLastError();
 }
 

@@ -137,6 +137,19 @@ PtStatus pt_render_tiles(PtContext *ctx, void *out_device_packed, PtStats *stats
  * to max_tiles_per_rank tiles (what a gather of equal-sized buffers yields), write the full W*H float4 frame. */
 PtStatus pt_unpack_tiles(PtContext *ctx, const void *gathered_device, uint32_t max_tiles_per_rank,
                          void *frame_device);
+/* Weighted partition.  xGMI is point-to-point, so the rank that assembles the frame receives every other rank's tiles
+ * over one link each while its own tiles cost no transfer: giving it a larger share balances render time against
+ * exchange time.  A context owns the tiles t with  first <= t % stride < first + run  (in increasing t; run = 0 owns
+ * nothing); pt_set_partition(rank, world) is pt_set_partition_ex(rank, 1, world).  Root weight k over N ranks:
+ * stride = N - 1 + k, root (0, k, stride), rank r >= 1 (k - 1 + r, 1, stride).  pt_tiles_count_ex counts a range's tiles
+ * for the current RenderSize; pt_render_tiles renders the context's range. */
+PtStatus pt_set_partition_ex(PtContext *ctx, uint32_t first, uint32_t run, uint32_t stride);
+uint32_t pt_tiles_count_ex(PtContext *ctx, uint32_t first, uint32_t run, uint32_t stride);
+/* Un-swizzle n_parts packed buffers laid out part_stride_px float4 apart, part i holding the tiles of the range
+ * (first0 + i * run, run, stride).  Pixels of tiles outside these ranges are left untouched, so the frame is assembled
+ * by one call for the root's own range and one for the gathered ranges. */
+PtStatus pt_unpack_tiles_ex(PtContext *ctx, const void *packed_device, uint64_t part_stride_px, uint32_t n_parts,
+                            uint32_t first0, uint32_t run, uint32_t stride, void *frame_device);
 
 /* Test / tooling hooks. */
 /* Closest hit of n rays against the current accel: o,d = n*3 floats (d unit length), tmin per call.

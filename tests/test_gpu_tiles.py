@@ -44,6 +44,52 @@ def test_partition_invariance(dxrs, host, renderer, w, h, spp, bounces, worlds):
         assert np.array_equal(img.view(np.uint32)[..., :3], full.view(np.uint32)[..., :3]), f"world={world}"
 
 
+@pytest.mark.parametrize("w,h,world,weight", [(1920, 1080, 8, 3), (1920, 1080, 2, 4), (200, 150, 3, 2), (200, 150, 4, 1), (333, 97, 5, 7), (200, 150, 3, 0)])
+def test_weighted_partition_invariance(dxrs, host, renderer, w, h, world, weight):
+    """root-weighted residue-range partition (pt_set_partition_ex / pt_unpack_tiles_ex): ranks emulated one after another;
+    the frame assembled from the root's own range + the gathered ranges is bit-identical to the full-frame render, and the
+    device un-swizzle agrees with the Python statement of the layout"""
+    import torch
+    from dxrs_amd import tiles
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    gs = dxrs.types.graphics_settings(w, h, frame_index=5, bounces=6, spp=1)
+    renderer.set_scene(spheres, materials, sd); renderer.set_camera(host.camera(w, h, jitter_index=5)); renderer.set_constants(gs)
+    renderer.set_partition(0, 1)
+    full, st = renderer.render()
+    ts2 = 32 * 32
+    root = tiles.weighted_partition(0, world, weight)
+    n_root = tiles.range_tiles_count(w, h, *root)
+    n_other = tiles.range_tiles_count(w, h, *tiles.weighted_partition(1, world, weight)) if weight else 0
+    assert renderer.tiles_count_ex(*root) == n_root
+    own = torch.zeros((n_root * ts2, 4), dtype=torch.float32, device="cuda")
+    others = torch.zeros((max(world - 1, 1), max(n_other, 1) * ts2, 4), dtype=torch.float32, device="cuda")
+    rays = 0
+    renderer.set_partition_ex(*root)
+    rays += renderer.render_tiles(own.data_ptr(), want_stats=True).rays
+    for rank in range(1, world):
+        rng_ = tiles.weighted_partition(rank, world, weight)
+        assert renderer.tiles_count_ex(*rng_) == tiles.range_tiles_count(w, h, *rng_)
+        renderer.set_partition_ex(*rng_)
+        stt = renderer.render_tiles(others[rank - 1].data_ptr(), want_stats=True)
+        rays += stt.rays
+    frame = torch.full((h, w, 4), -1.0, dtype=torch.float32, device="cuda")
+    renderer.unpack_tiles_ex(own.data_ptr(), 0, 1, root[0], root[1], root[2], frame.data_ptr())
+    if weight:
+        renderer.unpack_tiles_ex(others.data_ptr(), others.shape[1], world - 1, root[1], 1, root[2], frame.data_ptr())
+    renderer.synchronize()
+    out = frame.cpu().numpy()
+    assert rays == st.rays
+    assert np.array_equal(out.view(np.uint32)[..., :3], full.view(np.uint32)[..., :3])
+    ref = np.full((h, w, 4), -1.0, dtype=np.float32)
+    tiles.unpack_ranges(ref, [own.cpu().numpy().reshape(n_root, ts2, 4)], *root)
+    if weight:
+        tiles.unpack_ranges(ref, list(others.cpu().numpy().reshape(world - 1, -1, ts2, 4)), root[1], 1, root[2])
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    with pytest.raises(RuntimeError):
+        renderer.set_partition_ex(3, 2, 4)  # first + run > stride
+    renderer.set_partition(0, 1)
+
+
 def test_full_frame_determinism_and_counts(dxrs, host, renderer):
     """Full BASELINE C2 frame: run-to-run bit-identical although the queue order is decided by atomics; the ray count is
     consistent with the structure of the estimator (primaries + at most spp*bounces per pixel)."""
