@@ -48,6 +48,25 @@ class PtRect(C.Structure):
     _fields_ = [("x", C.c_uint32), ("y", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32)]
 
 
+class PtToneMapParams(C.Structure):
+    _fields_ = [("Operator", C.c_uint32), ("TransferFunction", C.c_uint32), ("LinearExposure", C.c_float), ("PaperWhiteNits", C.c_float),
+                ("ColorRotation", C.c_uint32), ("_pad", C.c_uint32 * 3)]
+
+
+TONE_NONE, TONE_SATURATE, TONE_REINHARD, TONE_ACES_FILMIC = 0, 1, 2, 3          # DirectX::ToneMapPostProcess::Operator
+TRANSFER_LINEAR, TRANSFER_SRGB, TRANSFER_ST2084 = 0, 1, 2                       # ::TransferFunction
+ROTATE_709_TO_2020, ROTATE_P3D65_TO_2020, ROTATE_709_TO_P3D65 = 0, 1, 2          # ::ColorPrimaryRotation
+
+
+def tonemap_params(operator=TONE_ACES_FILMIC, transfer=TRANSFER_SRGB, exposure_stops=0.0, paper_white_nits=200.0, rotation=ROTATE_709_TO_2020):
+    """the reference's defaults (Source/MyAppData.h:313-330): ACESFilmic + sRGB at exposure 0 for SDR, 200 nits / HDTV_to_UHDTV for HDR10"""
+    p = PtToneMapParams()
+    p.Operator, p.TransferFunction, p.ColorRotation = operator, transfer, rotation
+    p.LinearExposure = 2.0 ** exposure_stops  # SetExposure: linear exposure = 2^stops
+    p.PaperWhiteNits = paper_white_nits
+    return p
+
+
 class PtConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("tile_size", C.c_uint32), ("stream", C.c_uint64), ("flags", C.c_uint32), ("frames_in_flight", C.c_uint32)]
 

@@ -16,7 +16,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR
 # every symbol include/pt_api.h declares
 API_SYMBOLS = [
     "pt_create", "pt_destroy", "pt_set_scene", "pt_build_accel", "pt_update_spheres", "pt_refit_accel", "pt_set_camera", "pt_set_constants", "pt_render",
-    "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_set_partition_ex", "pt_tiles_count_ex", "pt_unpack_tiles_ex", "pt_trace_rays", "pt_trace_rays_stats", "pt_accel_download",
+    "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_set_partition_ex", "pt_tiles_count_ex", "pt_unpack_tiles_ex", "pt_tonemap", "pt_accumulate", "pt_trace_rays", "pt_trace_rays_stats", "pt_accel_download",
     "pt_accel_download_order", "pt_lbvh_build_host", "pt_set_profiling", "pt_get_profile", "pt_get_totals", "pt_get_queue_sizes", "pt_synchronize", "pt_last_error", "pt_version",
 ]
 
@@ -70,6 +70,10 @@ class HipLib:
         lib.pt_tiles_count_ex.argtypes = [vp, u32, u32, u32]
         lib.pt_unpack_tiles_ex.restype = C.c_int
         lib.pt_unpack_tiles_ex.argtypes = [vp, vp, C.c_uint64, u32, u32, u32, u32, vp]
+        lib.pt_tonemap.restype = C.c_int
+        lib.pt_tonemap.argtypes = [vp, vp, u32, vp, vp]
+        lib.pt_accumulate.restype = C.c_int
+        lib.pt_accumulate.argtypes = [vp, vp, vp, u32, u32]
         lib.pt_trace_rays.restype = C.c_int
         lib.pt_trace_rays.argtypes = [vp, vp, vp, u32, C.c_float, C.c_int, vp, vp]
         lib.pt_trace_rays_stats.restype = C.c_int
@@ -252,6 +256,14 @@ class Renderer:
 
     def unpack_tiles_ex(self, packed_ptr, part_stride_px, n_parts, first0, run, stride, frame_ptr):
         self._check(self._lib.pt_unpack_tiles_ex(self._ctx, C.c_void_p(packed_ptr), part_stride_px, n_parts, first0, run, stride, C.c_void_p(frame_ptr)))
+
+    def tonemap(self, hdr_ptr, n_pixels, params, out_ptr):
+        """display transform (row N3): device float4[n] -> device packed uint32[n], asynchronous on the context's stream"""
+        self._check(self._lib.pt_tonemap(self._ctx, C.c_void_p(hdr_ptr), n_pixels, C.addressof(params), C.c_void_p(out_ptr)))
+
+    def accumulate(self, accum_ptr, radiance_ptr, n_pixels, frames_accumulated):
+        """running mean of successive frames (device pointers), asynchronous on the context's stream"""
+        self._check(self._lib.pt_accumulate(self._ctx, C.c_void_p(accum_ptr), C.c_void_p(radiance_ptr), n_pixels, frames_accumulated))
 
     def trace_rays(self, origins, directions, tmin=0.0, use_bvh=True):
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)

@@ -912,6 +912,29 @@ PtStatus pt_unpack_tiles_ex(PtContext* c, const void* packed, uint64_t part_stri
     return PT_OK;
 }
 
+PtStatus pt_tonemap(PtContext* c, const void* hdr, uint32_t n_pixels, const PtToneMapParams* params, void* out)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!hdr || !out || !params) return fail(c, PT_ERR_INVALID_ARG, "pt_tonemap: null pointer");
+    if (params->Operator > kToneACESFilmic || params->TransferFunction > kTransferST2084 || params->ColorRotation > kRotate709toP3D65)
+        return fail(c, PT_ERR_INVALID_ARG, "pt_tonemap: unknown operator / transfer function / colour rotation");
+    if (n_pixels == 0) return PT_OK;
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, launch_tonemap(static_cast<const float4*>(hdr), static_cast<uint32_t*>(out), n_pixels, *params, c->stream));
+    return PT_OK;
+}
+
+PtStatus pt_accumulate(PtContext* c, void* accum, const void* radiance, uint32_t n_pixels, uint32_t frames_accumulated)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!accum || !radiance) return fail(c, PT_ERR_INVALID_ARG, "pt_accumulate: null pointer");
+    if (frames_accumulated == 0xFFFFFFFFu) return fail(c, PT_ERR_INVALID_ARG, "pt_accumulate: frame count overflow");
+    if (n_pixels == 0) return PT_OK;
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, launch_accumulate(static_cast<float4*>(accum), static_cast<const float4*>(radiance), n_pixels, frames_accumulated, c->stream));
+    return PT_OK;
+}
+
 static PtStatus trace_rays_impl(PtContext* c, const float* origins, const float* directions, uint32_t n, float tmin, int use_bvh, float* out_t,
                                 uint32_t* out_id, uint32_t* out_visits)
 {

@@ -749,6 +749,28 @@ __global__ void unpack_tiles_kernel(const float4* __restrict__ packed, float4* _
     }
 }
 
+// Row N3: display transform (20 B / pixel: HBM-bound) and progressive accumulation (48 B / pixel).
+__global__ void tonemap_kernel(const float4* __restrict__ hdr, uint32_t* __restrict__ out, uint32_t n, PtToneMapParams p)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 c = hdr[i];
+        out[i] = tonemap_pixel(make_f3(c.x, c.y, c.z), p);
+    }
+}
+
+__global__ void accumulate_kernel(float4* __restrict__ accum, const float4* __restrict__ rad, uint32_t n, float inv, int first)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 x = rad[i];
+        float4 a = first ? x : accum[i];
+        if (!first) {
+            a.x = accumulate_value(a.x, x.x, inv, false); a.y = accumulate_value(a.y, x.y, inv, false);
+            a.z = accumulate_value(a.z, x.z, inv, false); a.w = accumulate_value(a.w, x.w, inv, false);
+        }
+        accum[i] = a;
+    }
+}
+
 // totals[0] += sum of counts[1..n_iters] (secondary rays of this frame); one thread
 // Fold one parity's counters into the running total (pt_get_totals / stats); leaves them zeroed.
 __global__ void flush_counters_kernel(uint32_t* counts, uint32_t n_counts, unsigned long long* tail, unsigned long long* totals, uint32_t* host_counts)
@@ -886,6 +908,21 @@ hipError_t launch_unpack_tiles(const float4* packed, float4* frame, uint32_t w, 
     const uint32_t n = w * h;
     const uint32_t grid = (n + 255u) / 256u < 4096u ? (n + 255u) / 256u : 4096u;
     hipLaunchKernelGGL(unpack_tiles_kernel, dim3(grid), dim3(256), 0, stream, packed, frame, w, h, ts, tiles_x, first0, run, stride, n_parts, part_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_tonemap(const float4* hdr, uint32_t* out, uint32_t n, const PtToneMapParams& p, hipStream_t stream)
+{
+    const uint32_t grid = (n + 255u) / 256u < 8192u ? (n + 255u) / 256u : 8192u;
+    hipLaunchKernelGGL(tonemap_kernel, dim3(grid ? grid : 1u), dim3(256), 0, stream, hdr, out, n, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_accumulate(float4* accum, const float4* rad, uint32_t n, uint32_t frames_accumulated, hipStream_t stream)
+{
+    const uint32_t grid = (n + 255u) / 256u < 8192u ? (n + 255u) / 256u : 8192u;
+    const float inv = 1.0f / (float)(frames_accumulated + 1u);
+    hipLaunchKernelGGL(accumulate_kernel, dim3(grid ? grid : 1u), dim3(256), 0, stream, accum, rad, n, inv, frames_accumulated == 0 ? 1 : 0);
     return hipGetLastError();
 }
 

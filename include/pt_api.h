@@ -151,6 +151,18 @@ uint32_t pt_tiles_count_ex(PtContext *ctx, uint32_t first, uint32_t run, uint32_
 PtStatus pt_unpack_tiles_ex(PtContext *ctx, const void *packed_device, uint64_t part_stride_px, uint32_t n_parts,
                             uint32_t first0, uint32_t run, uint32_t stride, void *frame_device);
 
+/* Row N3 -- display transform and progressive accumulation, on the context's stream (asynchronous).
+ * pt_tonemap replaces App::Impl::ToneMap (Source/App.cpp:1731-1757, DirectXTK ToneMapPostProcess): hdr = n_pixels float4
+ * (r,g,b,_) -> out = n_pixels packed uint32: R8G8B8A8_UNORM for the Linear / SRGB transfer functions, R10G10B10A2_UNORM
+ * for ST2084.  Both pointers are DEVICE pointers.
+ * pt_accumulate keeps the running mean of successive frames (progressive refinement while the camera rests; the
+ * reference accumulates inside its denoisers, which are out of scope): accum = frames_accumulated == 0 ? radiance
+ * : accum + (radiance - accum) / (frames_accumulated + 1), per channel, alpha included. */
+PtStatus pt_tonemap(PtContext *ctx, const void *hdr_device, uint32_t n_pixels, const PtToneMapParams *params,
+                    void *out_device);
+PtStatus pt_accumulate(PtContext *ctx, void *accum_device, const void *radiance_device, uint32_t n_pixels,
+                       uint32_t frames_accumulated);
+
 /* Test / tooling hooks. */
 /* Closest hit of n rays against the current accel: o,d = n*3 floats (d unit length), tmin per call.
  * Outputs host arrays t[n], id[n] (id = 0xFFFFFFFF on miss).  use_bvh = 0 runs the device brute-force kernel. */

@@ -102,6 +102,17 @@ typedef struct PtGraphicsSettings {
     uint32_t _pad1[3];                           /* 68 */
 } PtGraphicsSettings;
 
+/* Display transform parameters (row N3): what App::Impl::ToneMap hands to DirectXTK's ToneMapPostProcess
+ * (Source/App.cpp:1731-1757; operator / transfer-function pairs created at Source/App.cpp:760-769). */
+typedef struct PtToneMapParams {
+    uint32_t Operator;         /* ToneMapPostProcess::Operator: 0 None, 1 Saturate, 2 Reinhard, 3 ACESFilmic */
+    uint32_t TransferFunction; /* ToneMapPostProcess::TransferFunction: 0 Linear, 1 SRGB, 2 ST2084 */
+    float LinearExposure;      /* SetExposure(stops) -> 2^stops (SDR paths) */
+    float PaperWhiteNits;      /* SetST2084Parameter (HDR10 path), default 200 (Source/MyAppData.h:316) */
+    uint32_t ColorRotation;    /* SetColorRotation: 0 HDTV_to_UHDTV, 1 DCI_P3_D65_to_UHDTV, 2 HDTV_to_DCI_P3_D65 */
+    uint32_t _pad[3];
+} PtToneMapParams;
+
 /* Pixel rectangle in render-target coordinates. */
 typedef struct PtRect {
     uint32_t x, y, w, h;
@@ -117,6 +128,7 @@ static_assert(sizeof(PtMaterial) == 64, "PtMaterial layout");
 static_assert(sizeof(PtCamera) == 608, "PtCamera layout");
 static_assert(sizeof(PtSceneData) == 80, "PtSceneData layout");
 static_assert(sizeof(PtGraphicsSettings) == 80, "PtGraphicsSettings layout");
+static_assert(sizeof(PtToneMapParams) == 32, "PtToneMapParams layout");
 #else
 _Static_assert(sizeof(PtSphere) == 16, "PtSphere layout");
 _Static_assert(sizeof(PtMaterial) == 64, "PtMaterial layout");

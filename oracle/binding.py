@@ -56,6 +56,8 @@ def declare_leaf_api(lib, prefix):
     fn("spawn_origin", None, [pf, pf, f, pf, pf])
     fn("primary_ray", None, [vp, u32, u32, u32, u32, pf, pf, pf, pf])
     fn("bsdf_step", None, [vp, C.c_int, pf, pf, pf, C.POINTER(OracleBsdfOut)])
+    fn("tonemap_pixel", u32, [pf, vp])
+    fn("accumulate", None, [vp, vp, u32, u32])
 
 
 class Oracle:
@@ -71,6 +73,8 @@ class Oracle:
         lib.oracle_trace_pixel.argtypes = [vp, vp, u32, vp, vp, vp, u32, u32, vp, u32, C.POINTER(u32)]
         lib.oracle_halton.restype = C.c_float
         lib.oracle_halton.argtypes = [u32, u32]
+        lib.oracle_tonemap.restype = None
+        lib.oracle_tonemap.argtypes = [vp, u32, vp, vp]
         declare_leaf_api(lib, "oracle_")
 
     def render(self, spheres, materials, scene_data, camera, gs, rect=None, row_step=1, threads=1):
@@ -87,6 +91,20 @@ class Oracle:
         if rc:
             raise RuntimeError(f"oracle_render failed ({rc})")
         return out, stats
+
+    def tonemap(self, hdr, params):
+        """hdr (..., 4) float32 -> packed uint32 (...): the display transform of row N3"""
+        hdr = np.ascontiguousarray(hdr, dtype=np.float32)
+        out = np.empty(hdr.shape[:-1], dtype=np.uint32)
+        self.lib.oracle_tonemap(hdr.ctypes.data, out.size, C.addressof(params), out.ctypes.data)
+        return out
+
+    def accumulate(self, accum, radiance, frames_accumulated):
+        """in-place running mean: accum (..., 4) float32 <- radiance"""
+        assert accum.flags.c_contiguous and accum.dtype == np.float32 and radiance.shape == accum.shape
+        radiance = np.ascontiguousarray(radiance, dtype=np.float32)
+        self.lib.oracle_accumulate(accum.ctypes.data, radiance.ctypes.data, accum.size // 4, frames_accumulated)
+        return accum
 
     def trace_pixel(self, spheres, materials, scene_data, camera, gs, px, py, max_events=4096):
         spheres = np.ascontiguousarray(spheres)

@@ -731,6 +731,74 @@ typedef struct {
     uint64_t rays, paths;
 } job_t;
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Row N3: display transform + progressive accumulation.
+ * App::Impl::ToneMap (Source/App.cpp:1731-1757) -> DirectXTK ToneMapPostProcess (un-vendored; operator / transfer pairs
+ * created at Source/App.cpp:760-769).  Shader arithmetic restated from the published ToneMap.fx (recollection):
+ *   SDR : c = hdr * linearExposure; Saturate | Reinhard c/(1+c) | ACESFilmic saturate(c(2.51c+.03)/(c(2.43c+.59)+.14));
+ *         SRGB: pow(|c|, 1/2.2)  -> R8G8B8A8_UNORM
+ *   HDR10: c = rotation * hdr; LinearToST2084(c * paperWhite / 10000)  -> R10G10B10A2_UNORM
+ * ---------------------------------------------------------------------------------------------------------------- */
+static float pow_pos(float x, float y) { return x > 0.0f ? oracle_pow(x, y) : 0.0f; }
+
+static float tone_operator(float x, uint32_t op)
+{
+    switch (op) {
+    case 1: return f_sat(x);
+    case 2: return x / (1.0f + x);
+    case 3: return f_sat((x * FMA(2.51f, x, 0.03f)) / FMA(x, FMA(2.43f, x, 0.59f), 0.14f));
+    default: return x;
+    }
+}
+
+static float srgb_est(float c) { return pow_pos(f_sat(c), 1.0f / 2.2f); }
+
+static float st2084(float y)
+{
+    float ym = pow_pos(f_min(f_abs(y), 1.0e30f), 0.1593017578f);
+    return pow_pos(FMA(18.8515625f, ym, 0.8359375f) / FMA(18.6875f, ym, 1.0f), 78.84375f);
+}
+
+static uint32_t to_unorm(float v, float scale) { return (uint32_t)FMA(f_sat(v), scale, 0.5f); }
+
+static const float k_rotation[3][9] = {
+    { 0.6274040f, 0.3292820f, 0.0433136f, 0.0690970f, 0.9195400f, 0.0113612f, 0.0163916f, 0.0880132f, 0.8955950f },     /* 709 -> 2020 */
+    { 0.753845f, 0.198593f, 0.047562f, 0.0457456f, 0.941777f, 0.0124772f, -0.00121055f, 0.0176041f, 0.983607f },        /* P3-D65 -> 2020 */
+    { 0.822461969f, 0.1775380f, 0.0f, 0.033194199f, 0.966805801f, 0.0f, 0.017082631f, 0.0723974f, 0.910519969f },       /* 709 -> P3-D65 */
+};
+
+uint32_t oracle_tonemap_pixel(const float hdr[3], const PtToneMapParams *p)
+{
+    if (p->TransferFunction == 2) {
+        const float *m = k_rotation[p->ColorRotation < 3 ? p->ColorRotation : 0];
+        v3 c = V3(hdr[0], hdr[1], hdr[2]);
+        float k = p->PaperWhiteNits * (1.0f / 10000.0f);
+        float r = st2084(v_dot(V3(m[0], m[1], m[2]), c) * k);
+        float g = st2084(v_dot(V3(m[3], m[4], m[5]), c) * k);
+        float b = st2084(v_dot(V3(m[6], m[7], m[8]), c) * k);
+        return to_unorm(r, 1023.0f) | (to_unorm(g, 1023.0f) << 10) | (to_unorm(b, 1023.0f) << 20) | (3u << 30);
+    }
+    float c[3];
+    for (int i = 0; i < 3; i++) {
+        c[i] = tone_operator(hdr[i] * p->LinearExposure, p->Operator);
+        if (p->TransferFunction == 1) c[i] = srgb_est(c[i]);
+    }
+    return to_unorm(c[0], 255.0f) | (to_unorm(c[1], 255.0f) << 8) | (to_unorm(c[2], 255.0f) << 16) | (255u << 24);
+}
+
+void oracle_tonemap(const float *hdr_rgba, uint32_t n_pixels, const PtToneMapParams *p, uint32_t *out)
+{
+    for (uint32_t i = 0; i < n_pixels; i++) out[i] = oracle_tonemap_pixel(hdr_rgba + 4u * i, p);
+}
+
+/* running mean over frames: n = frames already accumulated */
+void oracle_accumulate(float *accum_rgba, const float *radiance_rgba, uint32_t n_pixels, uint32_t frames_accumulated)
+{
+    float inv = 1.0f / (float)(frames_accumulated + 1u);
+    for (uint32_t i = 0; i < 4u * n_pixels; i++)
+        accum_rgba[i] = frames_accumulated == 0 ? radiance_rgba[i] : FMA(radiance_rgba[i] - accum_rgba[i], inv, accum_rgba[i]);
+}
+
 static void *worker(void *arg)
 {
     job_t *j = (job_t *)arg;

@@ -53,6 +53,11 @@ float oracle_log2(float x);
 float oracle_exp2(float x);
 float oracle_pow(float x, float y);
 float oracle_from_srgb(float c);
+
+/* row N3: display transform (Source/App.cpp:1731-1757 -> DirectXTK ToneMapPostProcess) and progressive accumulation */
+uint32_t oracle_tonemap_pixel(const float hdr[3], const PtToneMapParams *params);
+void oracle_tonemap(const float *hdr_rgba, uint32_t n_pixels, const PtToneMapParams *params, uint32_t *out);
+void oracle_accumulate(float *accum_rgba, const float *radiance_rgba, uint32_t n_pixels, uint32_t frames_accumulated);
 void oracle_get_basis(const float n[3], float t[3], float b[3]);
 void oracle_cosine_ray(const float u[2], float out[3]);
 void oracle_vndf_ray(const float u[2], float roughness, const float vlocal[3], float out[3]);

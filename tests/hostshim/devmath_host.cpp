@@ -2,6 +2,7 @@
 // csrc/pt_bsdf.h) as plain host C++ so tests can compare every leaf function bit-for-bit
 // with the CPU oracle without a GPU.  Not part of the product; never loaded by it.
 #include "../../directx-raytracing-spheres-demo_amd/csrc/pt_bsdf.h"
+#include "../../directx-raytracing-spheres-demo_amd/csrc/pt_post.h"
 
 using namespace pt;
 
@@ -60,6 +61,13 @@ void dev_primary_ray(const PtCamera* cam, uint32_t px, uint32_t py, uint32_t w, 
     f3 oo, dd;
     primary_ray(camera_params(*cam, w, h), px, py, oo, dd, *tmin, *tmax);
     o[0] = oo.x; o[1] = oo.y; o[2] = oo.z; d[0] = dd.x; d[1] = dd.y; d[2] = dd.z;
+}
+
+uint32_t dev_tonemap_pixel(const float hdr[3], const PtToneMapParams* p) { return tonemap_pixel(make_f3(hdr[0], hdr[1], hdr[2]), *p); }
+void dev_accumulate(float* accum, const float* rad, uint32_t n_pixels, uint32_t frames_accumulated)
+{
+    const float inv = 1.0f / (float)(frames_accumulated + 1u);
+    for (uint32_t i = 0; i < 4u * n_pixels; i++) accum[i] = accumulate_value(accum[i], rad[i], inv, frames_accumulated == 0);
 }
 
 struct DevBsdfOut {
