@@ -372,7 +372,10 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         const uint64_t e = (uint64_t)L.h_prev_counts[k] + L.h_prev_counts[k] / 4 + 64;
         return (uint32_t)std::min<uint64_t>(e, pm.n_slots);
     };
-    const uint32_t trav_cap = c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", 8);
+    // Persistent workgroups: with the BVH staged into LDS per workgroup, 2 per CU (= the 4 waves/SIMD the kernel is built
+    // for) amortise the 37 KB staging over ~4 batches of rays at 1080p / 1 spp (0.121 -> 0.116 ms per frame); with spp > 1
+    // the passes are long and uneven, and more, shorter workgroups balance better (C3: 6.77 vs 6.89 ms).
+    const uint32_t trav_cap = c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", spp == 1 && c->lds_scene ? 2 : 8);
     const uint32_t shade_cap = c->num_cus * env_u32("PT_SHADE_BLOCKS_PER_CU", 16);
     const uint32_t tail_cap = c->num_cus * env_u32("PT_TAIL_BLOCKS_PER_CU", 8);
     auto grid_for = [](uint32_t items, uint32_t threads, uint32_t cap) { return std::max(1u, std::min((items + threads - 1) / threads, cap)); };

@@ -363,11 +363,13 @@ struct PathState {
 // One iteration of the bounce-loop body (Raytracing.hlsl:213-364) for a path whose ray (ps.o, ps.d) has been traced to
 // (t, id); on sample end it accumulates into the pixel, and either finishes the pixel or regenerates the next sample
 // from the cached primary hit and keeps going.  Returns true when ps holds a new ray that must be traced.
+// kMulti = false specialises for SamplesPerPixel == 1: no radiance accumulator, no primary-hit cache, no sample
+// regeneration (and with it no camera parameters live across the bounce loop).
+template <bool kMulti>
 __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const Scratch& scratch,
                                            float4* __restrict__ out, PathState& ps, float t, uint32_t id)
 {
     const uint32_t slot = ps.slot;
-    const PixelRef pr = slot_to_pixel(pm, slot);
     for (;;) {
         // sampleRadiance so far is (dirty ? scratch : 0); srad_loaded says whether `srad` holds it
         f3 srad = make_f3(0.f, 0.f, 0.f);
@@ -378,7 +380,7 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
         if (id == kMissId) {
             const f3 env = environment_color(sv.env[0], sv.env[1], sv.env[2], sv.env[3], ps.d);
             if (ps.bounce == 0) {  // primary miss: pixel = environment (GBufferGeneration.hlsl:223-227; Raytracing.hlsl:249-252)
-                out[pr.out_index] = make_float4(env.x, env.y, env.z, 1.0f);
+                out[slot_to_pixel(pm, slot).out_index] = make_float4(env.x, env.y, env.z, 1.0f);
                 return false;
             }
             if (ps.dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
@@ -402,7 +404,7 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
                 srad_changed = true;
             }
             const bool last = ps.bounce == fp.bounces;
-            if (last && ps.sample + 1 == fp.spp) {
+            if (last && (!kMulti || ps.sample + 1 == fp.spp)) {
                 end_sample = true;  // the sample drawn on the final iteration is never used and no later sample reads the RNG
             } else {
                 const f3 Ns = hf.front ? hf.N : -hf.N;  // HitInfo.hlsli:60-64
@@ -450,10 +452,11 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
             if (ps.dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
         }
         f3 acc = make_f3(0.f, 0.f, 0.f);
-        if (ps.sample > 0) { const float4 r = scratch.radiance[slot]; acc = load3(r); }
+        if (kMulti && ps.sample > 0) { const float4 r = scratch.radiance[slot]; acc = load3(r); }
         const f3 total = acc + srad;
         ps.sample++;
-        if (ps.sample == fp.spp) {  // :378-385
+        const PixelRef pr = slot_to_pixel(pm, slot);
+        if (!kMulti || ps.sample == fp.spp) {  // :378-385
             f3 res = make_f3(0.f, 0.f, 0.f);
             if (is_finite(total.x) && is_finite(total.y) && is_finite(total.z)) {
                 res = total * fp.inv_spp;
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(kShadeThreads) void shade_kernel(SceneView sv, Pixe
         if (i < count) {
             ps = load_path(qin, i);
             const uint2 h = qin.hit[i];
-            if (ps.bounce != 0xFFu) emit = shade_step(sv, pm, fp, scratch, out, ps, as_float(h.x), h.y);
+            if (ps.bounce != 0xFFu) emit = shade_step<true>(sv, pm, fp, scratch, out, ps, as_float(h.x), h.y);
         }
         // ---- wave64 ballot + prefix compaction into the next queue; one atomic per block
         const unsigned long long mask = __ballot(emit);
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(SceneView sv, PixelM
             float t;
             uint32_t id;
             closest_hit<StackT>(nodes, sph, ids, sv.n, ps.o, ps.d, 0.0f, kInf, stack, blockDim.x, t, id);
-            if (!shade_step(sv, pm, fp, scratch, out, ps, t, id)) break;
+            if (!shade_step<true>(sv, pm, fp, scratch, out, ps, t, id)) break;
             my_rays++;  // rays spawned inside the tail (the input queue's rays are already in counts[])
         }
     }
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(SceneView sv, PixelM
 // queue (wave64 ballot + prefix, one atomic per workgroup) -- one wavefront bounce per launch, 96 B of queue traffic
 // per ray and no hit stream.  kLoop = true: the lane keeps alternating trace and shade_step until its pixel is done
 // (the persistent "tail" form for small queues).
-template <bool kLds, typename StackT, bool kPrimary, bool kLoop>
+template <bool kLds, typename StackT, bool kPrimary, bool kLoop, bool kMulti>
 // 4 waves/SIMD (<= 128 VGPRs): two 512-thread workgroups per CU with the BVH in LDS (the unconstrained build takes 134
 // VGPRs for the primary variant and drops to 3 waves/SIMD: measured 171 -> 149 us for the two compacting passes at C2)
 __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void bounce_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue qin, RayQueue qout,
@@ -641,9 +644,9 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
                     float t;
                     uint32_t id;
                     closest_hit<StackT>(nodes, sph, ids, sv.n, ps.o, ps.d, tmin, tmax, stack, blockDim.x, t, id);
-                    if (kPrimary && primary_trace && fp.spp > 1) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
+                    if (kMulti && kPrimary && primary_trace) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
                     primary_trace = false;
-                    emit = shade_step(sv, pm, fp, scratch, out, ps, t, id);
+                    emit = shade_step<kMulti>(sv, pm, fp, scratch, out, ps, t, id);
                     if (!kLoop || !emit) break;
                     my_rays++;  // a ray spawned inside the looping kernel (queued rays are counted by counts[])
                     tmin = 0.0f; tmax = kInf;
@@ -856,11 +859,13 @@ hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FramePar
     const bool small = sv.n_nodes < 32767u;
     const uint32_t elem = small ? 2u : 4u;
     const uint32_t lds = (sv.lds_scene ? scene_lds_bytes(sv.n_nodes, sv.n) : 0u) + threads * sv.stack_depth * elem;
-#define PT_BOUNCE3(L, T, P, LP)                                                                                            \
+#define PT_BOUNCE4(L, T, P, LP, M)                                                                                         \
     do {                                                                                                                    \
-        if (lds > 65536u) (void)hipFuncSetAttribute((const void*)bounce_kernel<L, T, P, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((bounce_kernel<L, T, P, LP>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out, fc); \
+        if (lds > 65536u) (void)hipFuncSetAttribute((const void*)bounce_kernel<L, T, P, LP, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((bounce_kernel<L, T, P, LP, M>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out, fc); \
     } while (0)
+#define PT_BOUNCE3(L, T, P, LP)                                                                                            \
+    do { if (fp.spp > 1) PT_BOUNCE4(L, T, P, LP, true); else PT_BOUNCE4(L, T, P, LP, false); } while (0)
 #define PT_BOUNCE2(L, T)                                                                                                    \
     do {                                                                                                                    \
         if (primary) { if (loop) PT_BOUNCE3(L, T, true, true); else PT_BOUNCE3(L, T, true, false); }                        \
@@ -870,6 +875,7 @@ hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FramePar
     else { if (small) PT_BOUNCE2(false, uint16_t); else PT_BOUNCE2(false, uint32_t); }
 #undef PT_BOUNCE2
 #undef PT_BOUNCE3
+#undef PT_BOUNCE4
     return hipGetLastError();
 }
 
