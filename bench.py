@@ -42,6 +42,8 @@ def main():
                          "frames' start; 0 = auto (3 on one GPU, 4 when the frame is split over several)")
     ap.add_argument("--animate", action="store_true",
                     help="demo scene in motion (closed-form springs + Moon orbit, 1/60 s per frame): per-frame sphere upload + LBVH refit inside the timed region")
+    ap.add_argument("--textures", action="store_true",
+                    help="demo scene with its textured objects (row N1: Alien-Metal, Moon, Earth; procedural stand-ins for the reference's image files)")
     ap.add_argument("--force-tiles", action="store_true", help="run the tile / gather / un-swizzle path even with one rank (rehearsal of the N > 1 path)")
     ap.add_argument("--root-weight", type=int, default=-1,
                     help="tiled path: shares of the frame rank 0 renders (every other rank renders one; 0 = rank 0 renders everything); "
@@ -88,6 +90,12 @@ def main():
     nbuf = args.frames_in_flight
     r = dxrs_amd.Renderer(device=local_rank, stream=stream, frames_in_flight=nbuf)
     accel = r.set_scene(spheres, materials, sd)
+    tex = None
+    if args.textures:
+        if args.scene != "demo":
+            raise SystemExit("--textures is defined for the demo scene")
+        tex = host.demo_textures(0, 0.0)
+        r.set_textures(tex)
     gs = graphics_settings(w, h, frame_index=0, bounces=args.bounces, spp=args.spp)
     r.set_constants(gs)
     cams = [host.camera(w, h, jitter_index=k, jitter_count=8) for k in range(8)]
@@ -202,6 +210,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.scene} sphere scene (seed {1 if args.scene == 'procedural' else 0}, {len(spheres)} spheres), {w}x{h}, {args.spp} spp, {args.bounces} bounces, RR on, sky env"
+                            + (", textured (Alien-Metal, Moon, Earth; procedural stand-in images)" if args.textures else "")
                             + (f", 32x32 tiles interleaved over {world} GPU(s) + RCCL gather to rank 0" if tiled else ""),
                 **({"tile_exchange": {"root_weight": ex.root_weight, "frames_per_gather": ex.batch, "root_tiles": ex.n_root,
                                       "tiles_per_other_rank": ex.n_other, "autotune": tune_log or None}} if tiled else {}),
@@ -251,6 +260,8 @@ def main():
         if args.frames_in_flight > 1 and not split:
             r1 = dxrs_amd.Renderer(device=local_rank, stream=stream, frames_in_flight=1)
             r1.set_scene(spheres, materials, sd); r1.set_constants(gs)
+            if tex is not None:
+                r1.set_textures(tex)
             if tiled:
                 r1.set_partition_ex(*ex.range)
             for k in range(3):
@@ -292,13 +303,13 @@ def main():
             while o_frames < 8 and o_time * cores < 15.0:
                 gs.FrameIndex = args.warmup + o_frames
                 t0c = time.perf_counter()
-                _, ost = oracle.render(spheres, materials, sd, cams[(args.warmup + o_frames) % 8], gs, row_step=args.cpu_row_step, threads=cores)
+                _, ost = oracle.render(spheres, materials, sd, cams[(args.warmup + o_frames) % 8], gs, row_step=args.cpu_row_step, threads=cores, textures=tex)
                 o_time += time.perf_counter() - t0c
                 o_rays += int(ost.rays)
                 o_frames += 1
             # single-thread figure: every 16th row of one frame
             t0c = time.perf_counter()
-            _, ost1 = oracle.render(spheres, materials, sd, cams[args.warmup % 8], gs, row_step=16, threads=1)
+            _, ost1 = oracle.render(spheres, materials, sd, cams[args.warmup % 8], gs, row_step=16, threads=1, textures=tex)
             t_single = time.perf_counter() - t0c
             result["cpu_baseline"] = {
                 "value": o_rays / o_time / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",

@@ -48,6 +48,23 @@ class PtRect(C.Structure):
     _fields_ = [("x", C.c_uint32), ("y", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32)]
 
 
+class PtTextureMapInfo(C.Structure):
+    _fields_ = [("Descriptor", C.c_uint32), ("TextureCoordinateIndex", C.c_uint32), ("_pad", C.c_uint32 * 2)]
+
+
+TEXTURE_MAP_BASE_COLOR, TEXTURE_MAP_EMISSIVE_COLOR, TEXTURE_MAP_METALLIC, TEXTURE_MAP_ROUGHNESS = 0, 1, 2, 3
+TEXTURE_MAP_METALLIC_ROUGHNESS, TEXTURE_MAP_TRANSMISSION, TEXTURE_MAP_NORMAL, TEXTURE_MAP_COUNT = 4, 5, 6, 7
+TEXTURE_RGBA8_UNORM, TEXTURE_RGBA8_UNORM_SRGB = 0, 1
+
+
+class PtObjectTextures(C.Structure):
+    _fields_ = [("Maps", PtTextureMapInfo * TEXTURE_MAP_COUNT)]
+
+
+class PtTexture(C.Structure):
+    _fields_ = [("Pixels", C.c_void_p), ("Width", C.c_uint32), ("Height", C.c_uint32), ("Format", C.c_uint32), ("_pad", C.c_uint32)]
+
+
 class PtToneMapParams(C.Structure):
     _fields_ = [("Operator", C.c_uint32), ("TransferFunction", C.c_uint32), ("LinearExposure", C.c_float), ("PaperWhiteNits", C.c_float),
                 ("ColorRotation", C.c_uint32), ("_pad", C.c_uint32 * 3)]

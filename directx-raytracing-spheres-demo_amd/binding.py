@@ -16,7 +16,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR
 # every symbol include/pt_api.h declares
 API_SYMBOLS = [
     "pt_create", "pt_destroy", "pt_set_scene", "pt_build_accel", "pt_update_spheres", "pt_refit_accel", "pt_set_camera", "pt_set_constants", "pt_render",
-    "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_set_partition_ex", "pt_tiles_count_ex", "pt_unpack_tiles_ex", "pt_tonemap", "pt_accumulate", "pt_trace_rays", "pt_trace_rays_stats", "pt_accel_download",
+    "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_set_partition_ex", "pt_tiles_count_ex", "pt_unpack_tiles_ex", "pt_tonemap", "pt_accumulate", "pt_set_textures", "pt_update_rotations", "pt_trace_rays", "pt_trace_rays_stats", "pt_accel_download",
     "pt_accel_download_order", "pt_lbvh_build_host", "pt_set_profiling", "pt_get_profile", "pt_get_totals", "pt_get_queue_sizes", "pt_synchronize", "pt_last_error", "pt_version",
 ]
 
@@ -70,6 +70,10 @@ class HipLib:
         lib.pt_tiles_count_ex.argtypes = [vp, u32, u32, u32]
         lib.pt_unpack_tiles_ex.restype = C.c_int
         lib.pt_unpack_tiles_ex.argtypes = [vp, vp, C.c_uint64, u32, u32, u32, u32, vp]
+        lib.pt_set_textures.restype = C.c_int
+        lib.pt_set_textures.argtypes = [vp, vp, u32, vp, vp]
+        lib.pt_update_rotations.restype = C.c_int
+        lib.pt_update_rotations.argtypes = [vp, vp, u32]
         lib.pt_tonemap.restype = C.c_int
         lib.pt_tonemap.argtypes = [vp, vp, u32, vp, vp]
         lib.pt_accumulate.restype = C.c_int
@@ -256,6 +260,18 @@ class Renderer:
 
     def unpack_tiles_ex(self, packed_ptr, part_stride_px, n_parts, first0, run, stride, frame_ptr):
         self._check(self._lib.pt_unpack_tiles_ex(self._ctx, C.c_void_p(packed_ptr), part_stride_px, n_parts, first0, run, stride, C.c_void_p(frame_ptr)))
+
+    def set_textures(self, texture_set):
+        """textures.TextureSet -> pt_set_textures (None removes all textures); call after set_scene"""
+        if texture_set is None:
+            self._check(self._lib.pt_set_textures(self._ctx, None, 0, None, None))
+            return
+        tex, n_tex, obj, rot = texture_set.as_ctypes()
+        self._check(self._lib.pt_set_textures(self._ctx, C.cast(tex, C.c_void_p), n_tex, C.cast(obj, C.c_void_p), rot.ctypes.data))
+
+    def update_rotations(self, rotations_xyzw):
+        q = np.ascontiguousarray(rotations_xyzw, dtype=np.float32).reshape(-1, 4)
+        self._check(self._lib.pt_update_rotations(self._ctx, q.ctypes.data, len(q)))
 
     def tonemap(self, hdr_ptr, n_pixels, params, out_ptr):
         """display transform (row N3): device float4[n] -> device packed uint32[n], asynchronous on the context's stream"""

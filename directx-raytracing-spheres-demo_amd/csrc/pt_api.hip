@@ -82,6 +82,13 @@ struct PtContext {
     std::vector<PtSphere> h_sph;
     bool scene_set = false;
 
+    // textures (row N1): table of linear float4 images + per-sphere map indices and rotations
+    std::vector<float4*> d_tex_images;
+    TexView* d_tex = nullptr;
+    uint32_t* d_tex_maps = nullptr;  // n * 8
+    float4* d_rot = nullptr;         // n
+    bool has_textures = false;
+
     // accel
     float4* d_nodes = nullptr;
     float4* d_sph_sorted = nullptr;
@@ -199,6 +206,14 @@ hipError_t sync_all(PtContext* c)
     return c->stream ? hipStreamSynchronize(c->stream) : hipSuccess;
 }
 
+void free_textures(PtContext* c)
+{
+    for (auto& img : c->d_tex_images) free_dev(img);
+    c->d_tex_images.clear();
+    free_dev(c->d_tex); free_dev(c->d_tex_maps); free_dev(c->d_rot);
+    c->has_textures = false;
+}
+
 PtStatus validate_frame(PtContext* c)
 {
     if (!c->scene_set) return fail(c, PT_ERR_STATE, "pt_set_scene has not been called");
@@ -222,6 +237,7 @@ SceneView make_scene_view(const PtContext* c, const Lane* L = nullptr)
     sv.stack_depth = std::max(1u, c->depth);
     sv.lds_scene = c->lds_scene ? 1u : 0u;
     for (int i = 0; i < 4; i++) sv.env[i] = c->sd.EnvironmentLightColor[i];
+    if (c->has_textures) { sv.tex = c->d_tex; sv.tex_maps = c->d_tex_maps; sv.rot = c->d_rot; }
     return sv;
 }
 
@@ -595,6 +611,7 @@ void pt_destroy(PtContext* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)sync_all(c);
+    free_textures(c);
     for (auto& L : c->lanes) {
         free_lane_buffers(L);
         free_lane_scene(L);
@@ -652,6 +669,7 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
     c->sd = *sd;
     c->scene_set = true;
     c->accel_valid = false;
+    free_textures(c);  // texture maps are per sphere: a new scene starts untextured
     for (auto& L : c->lanes) L.scene_private = false;  // every lane renders the new master scene
     return PT_OK;
 }
@@ -912,6 +930,77 @@ PtStatus pt_unpack_tiles_ex(PtContext* c, const void* packed, uint64_t part_stri
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, launch_unpack_tiles(static_cast<const float4*>(packed), static_cast<float4*>(frame), w, h, ts, (w + ts - 1) / ts, first0, run, stride,
                                   n_parts, part_stride_px, c->stream));
+    return PT_OK;
+}
+
+PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_textures, const PtObjectTextures* object_textures, const float* rotations)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!c->scene_set) return fail(c, PT_ERR_STATE, "pt_set_textures: call pt_set_scene first");
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, sync_all(c));
+    free_textures(c);
+    if (n_textures == 0) return PT_OK;
+    if (!textures || !object_textures) return fail(c, PT_ERR_INVALID_ARG, "pt_set_textures: null pointer");
+    const uint32_t n = c->n;
+    // validate before touching the device
+    for (uint32_t t = 0; t < n_textures; t++) {
+        const PtTexture& tx = textures[t];
+        if (!tx.Pixels || tx.Width == 0 || tx.Height == 0 || tx.Width > 16384 || tx.Height > 16384 || tx.Format > PT_TEXTURE_RGBA8_UNORM_SRGB)
+            return fail(c, PT_ERR_INVALID_ARG, "pt_set_textures: bad texture (null pixels, size outside 1..16384, or unknown format)");
+    }
+    std::vector<uint32_t> maps((size_t)n * 8u);
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t any = 0;
+        for (uint32_t k = 0; k < PT_TEXTURE_MAP_COUNT; k++) {
+            const PtTextureMapInfo& mi = object_textures[i].Maps[k];
+            if (mi.Descriptor != ~0u) {
+                if (mi.Descriptor >= n_textures) return fail(c, PT_ERR_INVALID_ARG, "pt_set_textures: Descriptor out of range");
+                if (mi.TextureCoordinateIndex != 0) return fail(c, PT_ERR_UNSUPPORTED, "pt_set_textures: spheres have one texture-coordinate set (index 0)");
+                any = 1;
+            }
+            maps[(size_t)i * 8u + k] = mi.Descriptor;
+        }
+        maps[(size_t)i * 8u + 7u] = any;
+    }
+    // 8-bit texels -> linear float4 (the conversion D3D's sampler does per fetch, done once; sRGB through from_srgb)
+    float unorm_lut[256], srgb_lut[256];
+    for (int v = 0; v < 256; v++) { unorm_lut[v] = (float)v * (1.0f / 255.0f); srgb_lut[v] = pt::from_srgb(unorm_lut[v]); }
+    std::vector<TexView> views(n_textures);
+    std::vector<float4> texels;
+    c->d_tex_images.assign(n_textures, nullptr);
+    for (uint32_t t = 0; t < n_textures; t++) {
+        const PtTexture& tx = textures[t];
+        const size_t count = (size_t)tx.Width * tx.Height;
+        texels.resize(count);
+        const uint8_t* px = static_cast<const uint8_t*>(tx.Pixels);
+        const float* lut = tx.Format == PT_TEXTURE_RGBA8_UNORM_SRGB ? srgb_lut : unorm_lut;
+        for (size_t i = 0; i < count; i++)
+            texels[i] = make_float4(lut[px[4 * i]], lut[px[4 * i + 1]], lut[px[4 * i + 2]], unorm_lut[px[4 * i + 3]]);
+        PT_HIP(c, hipMalloc(&c->d_tex_images[t], count * sizeof(float4)));
+        PT_HIP(c, hipMemcpy(c->d_tex_images[t], texels.data(), count * sizeof(float4), hipMemcpyHostToDevice));
+        views[t].texels = c->d_tex_images[t]; views[t].w = tx.Width; views[t].h = tx.Height;
+    }
+    PT_HIP(c, hipMalloc(&c->d_tex, n_textures * sizeof(TexView)));
+    PT_HIP(c, hipMemcpy(c->d_tex, views.data(), n_textures * sizeof(TexView), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMalloc(&c->d_tex_maps, maps.size() * sizeof(uint32_t)));
+    PT_HIP(c, hipMemcpy(c->d_tex_maps, maps.data(), maps.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    PT_HIP(c, hipMalloc(&c->d_rot, (size_t)n * sizeof(float4)));
+    c->has_textures = true;
+    return pt_update_rotations(c, rotations, n);
+}
+
+PtStatus pt_update_rotations(PtContext* c, const float* rotations, uint32_t n)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!c->has_textures) return fail(c, PT_ERR_STATE, "pt_update_rotations: the scene has no textures (rotations only orient texture coordinates)");
+    if (n != c->n) return fail(c, PT_ERR_INVALID_ARG, "pt_update_rotations: count differs from the scene's sphere count");
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, sync_all(c));
+    std::vector<float4> q((size_t)n, make_float4(0.f, 0.f, 0.f, 1.f));
+    if (rotations)
+        for (uint32_t i = 0; i < n; i++) q[i] = make_float4(rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]);
+    PT_HIP(c, hipMemcpy(c->d_rot, q.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));
     return PT_OK;
 }
 

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "pt_bsdf.h"
+#include "pt_texture.h"
 
 namespace pt {
 
@@ -41,6 +42,10 @@ struct SceneView {
     uint32_t stack_depth;       // traversal stack entries per lane
     uint32_t lds_scene;         // 1: kernels stage nodes + sph_sorted + sorted_id in LDS
     float env[4];               // SceneData.EnvironmentLightColor
+    // row N1 (textured spheres); null when the scene has no textures
+    const TexView* tex;         // texture table
+    const uint32_t* tex_maps;   // per sphere: 7 texture indices (TextureMapType order) + 1 "has any" flag
+    const float4* rot;          // per sphere: object rotation quaternion (x, y, z, w)
 };
 
 // ---- slot -> pixel mapping ---------------------------------------------------------------------------

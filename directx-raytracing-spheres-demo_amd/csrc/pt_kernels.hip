@@ -365,7 +365,10 @@ struct PathState {
 // from the cached primary hit and keeps going.  Returns true when ps holds a new ray that must be traced.
 // kMulti = false specialises for SamplesPerPixel == 1: no radiance accumulator, no primary-hit cache, no sample
 // regeneration (and with it no camera parameters live across the bounce loop).
-template <bool kMulti>
+// kTex = true adds EvaluateMaterial's texture branches + normal mapping (row N1; csrc/pt_texture.h).  It is a template
+// parameter of every kernel that shades, chosen per launch from SceneView::tex_maps, so the kernels of the untextured hot
+// path carry none of it (the textured fused kernels need 122-128 VGPRs against 101-107).
+template <bool kMulti, bool kTex = false>
 __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const Scratch& scratch,
                                            float4* __restrict__ out, PathState& ps, float t, uint32_t id)
 {
@@ -391,11 +394,29 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
             const float4 sp = sv.sph[id];
             const float4 m0 = sv.mats[id * 4 + 0], m1 = sv.mats[id * 4 + 1], m2 = sv.mats[id * 4 + 2], m3 = sv.mats[id * 4 + 3];
             hf = hit_frame(ps.o, ps.d, t, load3(sp), sp.w);
-            const f3 emission = make_f3(m1.y, m1.z, m1.w) * m1.x;  // Material::GetEmission
+            f3 base = load3(m0), emissive_color = make_f3(m1.y, m1.z, m1.w);
+            float metallic = m2.x, roughness = m2.y, transmission_m = m2.w;
+            f3 Ns = hf.front ? hf.N : -hf.N;  // HitInfo.hlsli:60-64
+            if (kTex && sv.tex_maps) {
+                const uint4* mp = reinterpret_cast<const uint4*>(sv.tex_maps + (size_t)id * 8u);
+                const uint4 ma = mp[0], mb = mp[1];
+                if (mb.w) {  // this sphere has at least one texture map
+                    const uint32_t maps[kMapCount] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z };
+                    const float4 q = sv.rot[id];
+                    const f3 n_obj = quat_rotate(-q.x, -q.y, -q.z, q.w, hf.N);  // world -> object: the conjugate rotation
+                    const f2 uv = sphere_uv(n_obj);
+                    f3 T = quat_rotate(q.x, q.y, q.z, q.w, sphere_tangent(n_obj));
+                    if (!hf.front) T = -T;  // HitInfo::GetFrontTangent
+                    const MaterialEval me = evaluate_material(sv.tex, maps, uv, base, m1.x, emissive_color, metallic, roughness, transmission_m, Ns, T);
+                    base = me.BaseColor; emissive_color = me.EmissiveColor; metallic = me.Metallic; roughness = me.Roughness;
+                    transmission_m = me.Transmission; Ns = me.Ns;
+                }
+            }
+            const f3 emission = emissive_color * m1.x;  // Material::GetEmission
             // bounce 0 mirrors the G-buffer round trip: Transmission = Metallic < 1 ? Transmission : 0 (Raytracing.hlsl:148)
-            const float transmission = (ps.bounce == 0 && !(m2.x < 1.0f)) ? 0.0f : m2.w;
+            const float transmission = (ps.bounce == 0 && !(metallic < 1.0f)) ? 0.0f : transmission_m;
             // m3.z / m3.w: dielectric F0 and 1/IOR, precomputed per material by pt_set_scene (padding words of PtMaterial)
-            const Bsdf bsdf = bsdf_init_pre(load3(m0), m2.x, m2.y, m2.z, m3.w, m3.z, transmission, hf.front);
+            const Bsdf bsdf = bsdf_init_pre(base, metallic, roughness, m2.z, m3.w, m3.z, transmission, hf.front);
             const bool t_finite = is_finite(ps.T.x) && is_finite(ps.T.y) && is_finite(ps.T.z);
             if (emission.x != 0.0f || emission.y != 0.0f || emission.z != 0.0f || !t_finite) {
                 if (ps.dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
@@ -407,7 +428,6 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
             if (last && (!kMulti || ps.sample + 1 == fp.spp)) {
                 end_sample = true;  // the sample drawn on the final iteration is never used and no later sample reads the RNG
             } else {
-                const f3 Ns = hf.front ? hf.N : -hf.N;  // HitInfo.hlsli:60-64
                 const Surf surf = surf_init(hf.front, hf.N, Ns);
                 const f3 V = -ps.d;
                 float w[3];
@@ -498,6 +518,7 @@ __device__ __forceinline__ void store_path(const RayQueue& q, uint32_t j, const 
     q.q2[j] = make_float4(ps.T.x, ps.T.y, ps.T.z, as_float(flags));
 }
 
+template <bool kTex>
 __global__ __launch_bounds__(kShadeThreads) void shade_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue qin, RayQueue qout,
                                                               Scratch scratch, float4* __restrict__ out,
                                                               const uint32_t* __restrict__ count_in_ptr, uint32_t* __restrict__ count_out_ptr)
@@ -514,7 +535,7 @@ __global__ __launch_bounds__(kShadeThreads) void shade_kernel(SceneView sv, Pixe
         if (i < count) {
             ps = load_path(qin, i);
             const uint2 h = qin.hit[i];
-            if (ps.bounce != 0xFFu) emit = shade_step<true>(sv, pm, fp, scratch, out, ps, as_float(h.x), h.y);
+            if (ps.bounce != 0xFFu) emit = shade_step<true, kTex>(sv, pm, fp, scratch, out, ps, as_float(h.x), h.y);
         }
         // ---- wave64 ballot + prefix compaction into the next queue; one atomic per block
         const unsigned long long mask = __ballot(emit);
@@ -538,7 +559,7 @@ __global__ __launch_bounds__(kShadeThreads) void shade_kernel(SceneView sv, Pixe
 // When the queue has become small, per-launch latency (dispatch + BVH staging + one traversal chain) dominates a
 // wavefront pass.  The tail kernel finishes every queued path in ONE launch: each lane alternates closest_hit and
 // shade_step in registers until its pixel is done (persistent threads; no queue traffic, no compaction).
-template <bool kLds, typename StackT>
+template <bool kLds, typename StackT, bool kTex>
 __global__ __launch_bounds__(kTailThreads) void tail_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue qin, Scratch scratch,
                                                             float4* __restrict__ out, const uint32_t* __restrict__ count_ptr,
                                                             unsigned long long* __restrict__ tail_rays)
@@ -568,7 +589,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(SceneView sv, PixelM
             float t;
             uint32_t id;
             closest_hit<StackT>(nodes, sph, ids, sv.n, ps.o, ps.d, 0.0f, kInf, stack, blockDim.x, t, id);
-            if (!shade_step<true>(sv, pm, fp, scratch, out, ps, t, id)) break;
+            if (!shade_step<true, kTex>(sv, pm, fp, scratch, out, ps, t, id)) break;
             my_rays++;  // rays spawned inside the tail (the input queue's rays are already in counts[])
         }
     }
@@ -585,7 +606,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(SceneView sv, PixelM
 // queue (wave64 ballot + prefix, one atomic per workgroup) -- one wavefront bounce per launch, 96 B of queue traffic
 // per ray and no hit stream.  kLoop = true: the lane keeps alternating trace and shade_step until its pixel is done
 // (the persistent "tail" form for small queues).
-template <bool kLds, typename StackT, bool kPrimary, bool kLoop, bool kMulti>
+template <bool kLds, typename StackT, bool kPrimary, bool kLoop, bool kMulti, bool kTex>
 // 4 waves/SIMD (<= 128 VGPRs): two 512-thread workgroups per CU with the BVH in LDS (the unconstrained build takes 134
 // VGPRs for the primary variant and drops to 3 waves/SIMD: measured 171 -> 149 us for the two compacting passes at C2)
 __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void bounce_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue qin, RayQueue qout,
@@ -646,7 +667,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
                     closest_hit<StackT>(nodes, sph, ids, sv.n, ps.o, ps.d, tmin, tmax, stack, blockDim.x, t, id);
                     if (kMulti && kPrimary && primary_trace) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
                     primary_trace = false;
-                    emit = shade_step<kMulti>(sv, pm, fp, scratch, out, ps, t, id);
+                    emit = shade_step<kMulti, kTex>(sv, pm, fp, scratch, out, ps, t, id);
                     if (!kLoop || !emit) break;
                     my_rays++;  // a ray spawned inside the looping kernel (queued rays are counted by counts[])
                     tmin = 0.0f; tmax = kInf;
@@ -654,6 +675,8 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
             }
         }
         if (!kLoop) {
+            // One atomic per WORKGROUP.  (One per wave -- no barriers, waves never wait for each other -- was measured and is
+            // far worse: 0.116 -> 0.201 ms per C2 frame; 8x as many same-address device-scope atomics from 8 XCDs serialise.)
             const unsigned long long mask = __ballot(emit);
             const uint32_t wave_n = __popcll(mask);
             const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
@@ -841,14 +864,16 @@ hipError_t launch_tail(const SceneView& sv, const PixelMap& pm, const FrameParam
     const bool small = sv.n_nodes < 32767u;
     const uint32_t elem = small ? 2u : 4u;
     const uint32_t lds = (sv.lds_scene ? scene_lds_bytes(sv.n_nodes, sv.n) : 0u) + kTailThreads * sv.stack_depth * elem;
-#define PT_TAIL(L, T)                                                                                                      \
+#define PT_TAIL2(L, T, X)                                                                                                  \
     do {                                                                                                                    \
-        if (lds > 65536u) (void)hipFuncSetAttribute((const void*)tail_kernel<L, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((tail_kernel<L, T>), dim3(grid), dim3(kTailThreads), lds, stream, sv, pm, fp, qin, scratch, out, count_ptr, tail_rays); \
+        if (lds > 65536u) (void)hipFuncSetAttribute((const void*)tail_kernel<L, T, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((tail_kernel<L, T, X>), dim3(grid), dim3(kTailThreads), lds, stream, sv, pm, fp, qin, scratch, out, count_ptr, tail_rays); \
     } while (0)
+#define PT_TAIL(L, T) do { if (sv.tex_maps) PT_TAIL2(L, T, true); else PT_TAIL2(L, T, false); } while (0)
     if (sv.lds_scene) { if (small) PT_TAIL(true, uint16_t); else PT_TAIL(true, uint32_t); }
     else { if (small) PT_TAIL(false, uint16_t); else PT_TAIL(false, uint32_t); }
 #undef PT_TAIL
+#undef PT_TAIL2
     return hipGetLastError();
 }
 
@@ -859,11 +884,13 @@ hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FramePar
     const bool small = sv.n_nodes < 32767u;
     const uint32_t elem = small ? 2u : 4u;
     const uint32_t lds = (sv.lds_scene ? scene_lds_bytes(sv.n_nodes, sv.n) : 0u) + threads * sv.stack_depth * elem;
-#define PT_BOUNCE4(L, T, P, LP, M)                                                                                         \
+#define PT_BOUNCE5(L, T, P, LP, M, X)                                                                                      \
     do {                                                                                                                    \
-        if (lds > 65536u) (void)hipFuncSetAttribute((const void*)bounce_kernel<L, T, P, LP, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((bounce_kernel<L, T, P, LP, M>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out, fc); \
+        if (lds > 65536u) (void)hipFuncSetAttribute((const void*)bounce_kernel<L, T, P, LP, M, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((bounce_kernel<L, T, P, LP, M, X>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out, fc); \
     } while (0)
+#define PT_BOUNCE4(L, T, P, LP, M)                                                                                         \
+    do { if (sv.tex_maps) PT_BOUNCE5(L, T, P, LP, M, true); else PT_BOUNCE5(L, T, P, LP, M, false); } while (0)
 #define PT_BOUNCE3(L, T, P, LP)                                                                                            \
     do { if (fp.spp > 1) PT_BOUNCE4(L, T, P, LP, true); else PT_BOUNCE4(L, T, P, LP, false); } while (0)
 #define PT_BOUNCE2(L, T)                                                                                                    \
@@ -876,13 +903,15 @@ hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FramePar
 #undef PT_BOUNCE2
 #undef PT_BOUNCE3
 #undef PT_BOUNCE4
+#undef PT_BOUNCE5
     return hipGetLastError();
 }
 
 hipError_t launch_shade(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const RayQueue& qout,
                         const Scratch& scratch, float4* out, const uint32_t* count_in, uint32_t* count_out, uint32_t grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL(shade_kernel, dim3(grid), dim3(kShadeThreads), 0, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out);
+    if (sv.tex_maps) hipLaunchKernelGGL(shade_kernel<true>, dim3(grid), dim3(kShadeThreads), 0, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out);
+    else hipLaunchKernelGGL(shade_kernel<false>, dim3(grid), dim3(kShadeThreads), 0, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out);
     return hipGetLastError();
 }
 

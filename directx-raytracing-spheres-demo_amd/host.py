@@ -53,6 +53,32 @@ class HostLib:
             raise ValueError(f"pth_scene_at_time failed ({rc})")
         return spheres
 
+    def demo_textures(self, seed=0, time=0.0):
+        """TextureSet of the demo scene's textured objects (Alien-Metal, Moon, Earth: Source/MyScene.ixx:161-166, 285-295)
+        at simulation time `time`, as the C++ host mirror builds it (MySceneDesc(seed, textured=true); procedural stand-ins
+        for the reference's image files unless a loader is installed on the C++ side)."""
+        from .abi_types import TEXTURE_MAP_COUNT, TEXTURE_RGBA8_UNORM_SRGB, PtObjectTextures
+        from .textures import TextureSet
+        self.lib.pth_demo_textures.restype = C.c_int
+        self.lib.pth_demo_textures.argtypes = [C.c_uint32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        nt, no, nb = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+        self.lib.pth_demo_textures(seed, time, C.byref(nt), C.byref(no), C.byref(nb), None, None, None, None)
+        info = np.zeros((nt.value, 4), dtype=np.uint32)
+        pixels = np.zeros(nb.value, dtype=np.uint8)
+        obj = (PtObjectTextures * no.value)()
+        rot = np.zeros((no.value, 4), dtype=np.float32)
+        rc = self.lib.pth_demo_textures(seed, time, C.byref(nt), C.byref(no), C.byref(nb), info.ctypes.data, pixels.ctypes.data, C.addressof(obj), rot.ctypes.data)
+        if rc:
+            raise ValueError(f"pth_demo_textures failed ({rc})")
+        ts = TextureSet(no.value)
+        for (w, h, fmt, off) in info:
+            ts.add_image(pixels[off:off + int(w) * int(h) * 4].reshape(int(h), int(w), 4).copy(), srgb=fmt == TEXTURE_RGBA8_UNORM_SRGB)
+        for i in range(no.value):
+            for k in range(TEXTURE_MAP_COUNT):
+                ts.maps[i, k] = obj[i].Maps[k].Descriptor
+        ts.rotations[:] = rot
+        return ts
+
     def camera(self, width, height, position=(0.0, 0.0, -15.0), look_at=None, hfov=math.pi / 2, jitter=True, jitter_index=0, jitter_count=8):
         """Demo camera (MyScene.ixx:90; HFOV 90 deg, MyAppData.h:177); jitter = Halton2D(index + 1) - 0.5 cycling mod 8."""
         cam = PtCamera()

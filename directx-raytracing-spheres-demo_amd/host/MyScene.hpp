@@ -129,8 +129,10 @@ inline RenderObjectDesc Star()  // MyScene.ixx:258-267: the mirror "ground"
 }  // namespace detail
 
 // The demo default scene.  The reference seeds from random_device; the build takes a seed.
+// `textured` = false is the benchmark configuration of SURVEY 8d ("textures off"); true attaches the texture files the
+// reference names for Alien-Metal, Moon and Earth (MyScene.ixx:161-166, 285-295) -- resolved by the Scene's texture loader.
 struct MySceneDesc : SceneDesc {
-    explicit MySceneDesc(unsigned seed = 0)
+    explicit MySceneDesc(unsigned seed = 0, bool textured = false)
     {
         Camera.Position.z = -15;  // MyScene.ixx:90
         detail::AddHeroes(*this);
@@ -138,6 +140,23 @@ struct MySceneDesc : SceneDesc {
         RenderObjects.emplace_back(detail::Moon());
         RenderObjects.emplace_back(detail::Earth());
         RenderObjects.emplace_back(detail::Star());
+        if (textured) {
+            const std::string dir = "Assets/Textures/";  // MyScene.ixx:92
+            for (auto& o : RenderObjects) {
+                if (o.Name == ObjectNames::AlienMetal) {
+                    o.Textures[TextureMapType::BaseColor] = dir + "Alien-Metal_Albedo.png";
+                    o.Textures[TextureMapType::Metallic] = dir + "Alien-Metal_Metallic.png";
+                    o.Textures[TextureMapType::Roughness] = dir + "Alien-Metal_Roughness.png";
+                    o.Textures[TextureMapType::Normal] = dir + "Alien-Metal_Normal.png";
+                } else if (o.Name == ObjectNames::Moon) {
+                    o.Textures[TextureMapType::BaseColor] = dir + "Moon_BaseColor.jpg";
+                    o.Textures[TextureMapType::Normal] = dir + "Moon_Normal.jpg";
+                } else if (o.Name == ObjectNames::Earth) {
+                    o.Textures[TextureMapType::BaseColor] = dir + "Earth_BaseColor.jpg";
+                    o.Textures[TextureMapType::Normal] = dir + "Earth_Normal.jpg";
+                }
+            }
+        }
     }
 };
 
@@ -148,7 +167,7 @@ struct MySceneDesc : SceneDesc {
 //   * Moon: circular orbit of period 10 s around the Earth in the xz-plane (MyScene.ixx:240-248,270-277)
 //   * Earth / Star gravity on the other bodies is off by default (userData = false), their spin only matters with textures.
 struct MyScene : Scene {
-    explicit MyScene(unsigned seed = 0) { Load(MySceneDesc(seed)); m_initial = Desc.RenderObjects; }
+    explicit MyScene(unsigned seed = 0, bool textured = false) { Load(MySceneDesc(seed, textured)); m_initial = Desc.RenderObjects; }
 
     bool IsStatic() const { return !m_isPhysXRunning; }
     void SetRunning(bool running) { m_isPhysXRunning = running; }
@@ -177,6 +196,9 @@ struct MyScene : Scene {
                 const float theta = kTwoPi / 10.0f * t;  // OrbitalPeriod = 10 (MyScene.ixx:244)
                 const float R = 4.0f;                     // |earth - moon| at t = 0
                 o.Position = { -R * std::cos(theta), o0.Position.y, R * std::sin(theta) };
+                o.Rotation = Quaternion::CreateFromAxisAngle({ 0, 1, 0 }, theta);  // tidally locked: angular velocity = v / R (MyScene.ixx:283)
+            } else if (o.Name == ObjectNames::Earth) {
+                o.Rotation = Quaternion::CreateFromAxisAngle({ 0, 1, 0 }, kTwoPi / 15.0f * t);  // RotationPeriod = 15 (MyScene.ixx:253, 289)
             }
         }
         Refresh();

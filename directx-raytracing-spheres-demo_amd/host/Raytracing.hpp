@@ -64,7 +64,20 @@ struct Raytracing {
         ThrowIfFailed(pt_set_scene(m_ctx, scene.GetSpheres().data(), scene.GetMaterials().data(), scene.GetObjectCount(), &sd), m_ctx, "pt_set_scene");
         PtAccelInfo info{};
         ThrowIfFailed(pt_build_accel(m_ctx, &info), m_ctx, "pt_build_accel");
+        if (scene.HasTextures()) {  // ObjectData::TextureMapInfoArray + the texture uploads of Scene::Load (Scene.ixx:150-180)
+            std::vector<PtTexture> textures;
+            for (const auto& t : scene.GetTextures()) textures.push_back(t.ToPt());
+            ThrowIfFailed(pt_set_textures(m_ctx, textures.data(), static_cast<uint32_t>(textures.size()), scene.GetObjectTextures().data(),
+                                          scene.GetRotations().data()), m_ctx, "pt_set_textures");
+        }
         return info;
+    }
+
+    // the poses of a running scene (MyScene::Tick -> Scene::Refresh): rotations only orient texture coordinates
+    void UpdateRotations(const Scene& scene)
+    {
+        if (scene.HasTextures())
+            ThrowIfFailed(pt_update_rotations(m_ctx, scene.GetRotations().data(), scene.GetObjectCount()), m_ctx, "pt_update_rotations");
     }
 
     void SetCamera(const Camera& camera)

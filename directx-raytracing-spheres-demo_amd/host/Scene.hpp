@@ -7,8 +7,12 @@
 #include <string>
 #include <vector>
 
+#include <array>
+#include <map>
+
 #include "Camera.hpp"
 #include "Material.hpp"
+#include "Texture.hpp"
 
 namespace dxrs {
 
@@ -17,6 +21,8 @@ struct RenderObjectDesc {
     Float3 Position;       // PhysX-space centre (z is flipped on Refresh)
     float Radius = 0.5f;   // PxSphereGeometry radius
     dxrs::Material Material;
+    Quaternion Rotation;   // PhysX-space pose rotation (mirrored with the position on Refresh)
+    std::array<std::string, TextureMapType::Count> Textures;  // file per TextureMapType, empty = none (Scene.ixx:40)
 };
 
 struct SceneDesc {
@@ -36,9 +42,29 @@ struct SceneDesc {
 struct Scene {
     SceneDesc Desc;
 
+    void SetTextureLoader(TextureLoader loader) { m_loader = std::move(loader); }
+
+    // Scene::Load (Scene.ixx:123-180): every distinct texture file is loaded once and shared by the objects that name it
     void Load(const SceneDesc& sceneDesc)
     {
         Desc = sceneDesc;
+        m_textures.clear();
+        m_objectTextures.assign(Desc.RenderObjects.size(), PtObjectTextures{});
+        std::map<std::pair<std::string, uint32_t>, uint32_t> loaded;
+        for (size_t i = 0; i < Desc.RenderObjects.size(); i++)
+            for (uint32_t k = 0; k < TextureMapType::Count; k++) {
+                auto& info = m_objectTextures[i].Maps[k];
+                info.Descriptor = ~0u;
+                const auto& path = Desc.RenderObjects[i].Textures[k];
+                if (path.empty()) continue;
+                const auto key = std::make_pair(path, k);
+                auto it = loaded.find(key);
+                if (it == loaded.end()) {
+                    m_textures.emplace_back(m_loader ? m_loader(path, k) : DefaultTextureLoader(path, k));
+                    it = loaded.emplace(key, static_cast<uint32_t>(m_textures.size() - 1)).first;
+                }
+                info.Descriptor = it->second;
+            }
         Refresh();
     }
 
@@ -48,16 +74,24 @@ struct Scene {
         const auto n = Desc.RenderObjects.size();
         m_spheres.resize(n);
         m_materials.resize(n);
+        m_rotations.resize(4 * n);
         for (size_t i = 0; i < n; i++) {
             const auto& o = Desc.RenderObjects[i];
             m_spheres[i] = PtSphere{ o.Position.x, o.Position.y, -o.Position.z, o.Radius };
             m_materials[i] = ToPt(o.Material);
+            // the z mirror diag(1,1,-1) conjugates a rotation (x, y, z, w) into (-x, -y, z, w)
+            m_rotations[4 * i] = -o.Rotation.x; m_rotations[4 * i + 1] = -o.Rotation.y;
+            m_rotations[4 * i + 2] = o.Rotation.z; m_rotations[4 * i + 3] = o.Rotation.w;
         }
     }
 
     uint32_t GetObjectCount() const noexcept { return static_cast<uint32_t>(m_spheres.size()); }
     const std::vector<PtSphere>& GetSpheres() const noexcept { return m_spheres; }
     const std::vector<PtMaterial>& GetMaterials() const noexcept { return m_materials; }
+    bool HasTextures() const noexcept { return !m_textures.empty(); }
+    const std::vector<Texture>& GetTextures() const noexcept { return m_textures; }
+    const std::vector<PtObjectTextures>& GetObjectTextures() const noexcept { return m_objectTextures; }
+    const std::vector<float>& GetRotations() const noexcept { return m_rotations; }  // n x (x, y, z, w), world space
 
     // SceneData as uploaded by App::UpdateScene (Source/App.cpp:977-990) with no environment texture.
     PtSceneData GetSceneData() const
@@ -76,6 +110,10 @@ struct Scene {
 private:
     std::vector<PtSphere> m_spheres;
     std::vector<PtMaterial> m_materials;
+    std::vector<float> m_rotations;
+    std::vector<Texture> m_textures;
+    std::vector<PtObjectTextures> m_objectTextures;
+    TextureLoader m_loader;
 };
 
 }  // namespace dxrs

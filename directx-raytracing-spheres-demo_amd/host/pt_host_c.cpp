@@ -42,6 +42,34 @@ int pth_scene(uint32_t kind, uint32_t seed, uint32_t count_param, PtSphere* sphe
     }
 }
 
+// The demo scene with its textured objects (MySceneDesc(seed, true)) at simulation time `time`: texture table, per-object
+// maps and world-space rotations.  Two-step protocol: call with null arrays for the counts, then with storage.
+//   image_info[4 * t] = { width, height, format (PtTexture::Format), byte offset into `pixels` }
+int pth_demo_textures(uint32_t seed, double time, uint32_t* n_textures, uint32_t* n_objects, uint64_t* pixel_bytes,
+                      uint32_t* image_info, uint8_t* pixels, PtObjectTextures* object_textures, float* rotations)
+{
+    MyScene scene(seed, true);
+    scene.SetTime(time);
+    const auto& tex = scene.GetTextures();
+    uint64_t bytes = 0;
+    for (const auto& t : tex) bytes += t.Pixels.size();
+    if (n_textures) *n_textures = static_cast<uint32_t>(tex.size());
+    if (n_objects) *n_objects = scene.GetObjectCount();
+    if (pixel_bytes) *pixel_bytes = bytes;
+    if (!image_info || !pixels || !object_textures || !rotations) return 0;
+    uint64_t off = 0;
+    for (size_t t = 0; t < tex.size(); t++) {
+        image_info[4 * t] = tex[t].Width; image_info[4 * t + 1] = tex[t].Height;
+        image_info[4 * t + 2] = tex[t].ForceSRGB ? PT_TEXTURE_RGBA8_UNORM_SRGB : PT_TEXTURE_RGBA8_UNORM;
+        image_info[4 * t + 3] = static_cast<uint32_t>(off);
+        std::memcpy(pixels + off, tex[t].Pixels.data(), tex[t].Pixels.size());
+        off += tex[t].Pixels.size();
+    }
+    std::memcpy(object_textures, scene.GetObjectTextures().data(), scene.GetObjectCount() * sizeof(PtObjectTextures));
+    std::memcpy(rotations, scene.GetRotations().data(), scene.GetRotations().size() * sizeof(float));
+    return 0;
+}
+
 // CameraController at `position` with identity rotation (or looking at `look_at` when non-null), SetLens(hfov, w/h),
 // jitter = Halton2D(jitter_index + 1) - 0.5 when jitter_enabled (Source/App.cpp:542-551), jitter_index cycling mod jitter_count.
 void pth_camera(const float position[3], const float* look_at, float hfov, uint32_t width, uint32_t height, int jitter_enabled,

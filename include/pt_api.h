@@ -151,6 +151,19 @@ uint32_t pt_tiles_count_ex(PtContext *ctx, uint32_t first, uint32_t run, uint32_
 PtStatus pt_unpack_tiles_ex(PtContext *ctx, const void *packed_device, uint64_t part_stride_px, uint32_t n_parts,
                             uint32_t first0, uint32_t run, uint32_t stride, void *frame_device);
 
+/* Row N1 -- textured spheres: EvaluateMaterial's texture branches + normal mapping (Shaders/ShadingHelpers.hlsli:53-103,
+ * 161-235) over analytic sphere UVs / tangents (csrc/pt_texture.h).  Replaces the texture part of Scene::Load
+ * (Source/Scene.ixx:123-180: per-object Textures -> TextureMapInfoArray in ObjectData).  Call after pt_set_scene:
+ *   textures[n_textures]   decoded images (copied; converted to linear float4 on upload)
+ *   object_textures[n]     one TextureMapInfoArray per sphere (n = the scene's sphere count); Descriptor < n_textures or ~0u
+ *   rotations              n unit quaternions (x, y, z, w): object -> world rotation of each sphere, NULL = identity
+ * n_textures == 0 removes all textures.  Every kernel that shades has a textured variant, selected per launch.
+ * pt_update_rotations replaces the quaternions (Earth's spin, the Moon's tidal lock: Source/MyScene.ixx:240-291); it
+ * waits for the frames in flight. */
+PtStatus pt_set_textures(PtContext *ctx, const PtTexture *textures, uint32_t n_textures,
+                         const PtObjectTextures *object_textures, const float *rotations);
+PtStatus pt_update_rotations(PtContext *ctx, const float *rotations, uint32_t n);
+
 /* Row N3 -- display transform and progressive accumulation, on the context's stream (asynchronous).
  * pt_tonemap replaces App::Impl::ToneMap (Source/App.cpp:1731-1757, DirectXTK ToneMapPostProcess): hdr = n_pixels float4
  * (r,g,b,_) -> out = n_pixels packed uint32: R8G8B8A8_UNORM for the Linear / SRGB transfer functions, R10G10B10A2_UNORM

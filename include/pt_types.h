@@ -102,6 +102,33 @@ typedef struct PtGraphicsSettings {
     uint32_t _pad1[3];                           /* 68 */
 } PtGraphicsSettings;
 
+/* Row N1 -- textured spheres.  TextureMapInfo mirrors Shaders/Material.hlsli:39-43 / Source/Material.ixx:35-38 (16 bytes);
+ * Descriptor indexes the PtTexture array given to pt_set_textures instead of a D3D12 descriptor heap. */
+typedef struct PtTextureMapInfo {
+    uint32_t Descriptor;              /* ~0u = no texture */
+    uint32_t TextureCoordinateIndex;  /* spheres have one UV set: must be 0 */
+    uint32_t _pad[2];
+} PtTextureMapInfo;
+
+enum { PT_TEXTURE_MAP_BASE_COLOR = 0, PT_TEXTURE_MAP_EMISSIVE_COLOR = 1, PT_TEXTURE_MAP_METALLIC = 2, PT_TEXTURE_MAP_ROUGHNESS = 3,
+       PT_TEXTURE_MAP_METALLIC_ROUGHNESS = 4, PT_TEXTURE_MAP_TRANSMISSION = 5, PT_TEXTURE_MAP_NORMAL = 6, PT_TEXTURE_MAP_COUNT = 7 };
+
+/* TextureMapInfoArray of one object (Shaders/Common.hlsli:27, ObjectData::TextureMapInfoArray) */
+typedef struct PtObjectTextures {
+    PtTextureMapInfo Maps[PT_TEXTURE_MAP_COUNT];
+} PtObjectTextures;
+
+/* A decoded image as the reference's TextureHelpers hands it to D3D12 (Source/TextureHelpers.ixx:34-60): 8-bit RGBA texels,
+ * either linear (DXGI_FORMAT_R8G8B8A8_UNORM) or sRGB-encoded colour (.._UNORM_SRGB, `forceSRGB`); alpha is always linear. */
+typedef struct PtTexture {
+    const void *Pixels;    /* host pointer, Width * Height * 4 bytes, row-major, tightly packed */
+    uint32_t Width, Height;
+    uint32_t Format;       /* PT_TEXTURE_RGBA8_UNORM | PT_TEXTURE_RGBA8_UNORM_SRGB */
+    uint32_t _pad;
+} PtTexture;
+
+enum { PT_TEXTURE_RGBA8_UNORM = 0, PT_TEXTURE_RGBA8_UNORM_SRGB = 1 };
+
 /* Display transform parameters (row N3): what App::Impl::ToneMap hands to DirectXTK's ToneMapPostProcess
  * (Source/App.cpp:1731-1757; operator / transfer-function pairs created at Source/App.cpp:760-769). */
 typedef struct PtToneMapParams {
@@ -129,6 +156,7 @@ static_assert(sizeof(PtCamera) == 608, "PtCamera layout");
 static_assert(sizeof(PtSceneData) == 80, "PtSceneData layout");
 static_assert(sizeof(PtGraphicsSettings) == 80, "PtGraphicsSettings layout");
 static_assert(sizeof(PtToneMapParams) == 32, "PtToneMapParams layout");
+static_assert(sizeof(PtTextureMapInfo) == 16 && sizeof(PtObjectTextures) == 112, "TextureMapInfoArray layout");
 #else
 _Static_assert(sizeof(PtSphere) == 16, "PtSphere layout");
 _Static_assert(sizeof(PtMaterial) == 64, "PtMaterial layout");

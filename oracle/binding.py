@@ -16,6 +16,10 @@ class OracleBsdfOut(C.Structure):
     _fields_ = [("lobe", C.c_int), ("valid", C.c_int), ("L", C.c_float * 3), ("pdf", C.c_float), ("f", C.c_float * 3), ("weights", C.c_float * 3)]
 
 
+class OracleTextures(C.Structure):
+    _fields_ = [("textures", C.c_void_p), ("n_textures", C.c_uint32), ("object_textures", C.c_void_p), ("rotations", C.c_void_p)]
+
+
 class _Rect(C.Structure):
     _fields_ = [("x", C.c_uint32), ("y", C.c_uint32), ("w", C.c_uint32), ("h", C.c_uint32)]
 
@@ -56,6 +60,11 @@ def declare_leaf_api(lib, prefix):
     fn("spawn_origin", None, [pf, pf, f, pf, pf])
     fn("primary_ray", None, [vp, u32, u32, u32, u32, pf, pf, pf, pf])
     fn("bsdf_step", None, [vp, C.c_int, pf, pf, pf, C.POINTER(OracleBsdfOut)])
+    fn("atan2", f, [f, f])
+    fn("sphere_uv", None, [pf, pf])
+    fn("sphere_tangent", None, [pf, pf])
+    fn("quat_rotate", None, [pf, pf, pf])
+    fn("perturb_normal", None, [pf, pf, f, f, pf])
     fn("tonemap_pixel", u32, [pf, vp])
     fn("accumulate", None, [vp, vp, u32, u32])
 
@@ -73,12 +82,29 @@ class Oracle:
         lib.oracle_trace_pixel.argtypes = [vp, vp, u32, vp, vp, vp, u32, u32, vp, u32, C.POINTER(u32)]
         lib.oracle_halton.restype = C.c_float
         lib.oracle_halton.argtypes = [u32, u32]
+        lib.oracle_render_textured.restype = C.c_int
+        lib.oracle_render_textured.argtypes = [vp, vp, u32, vp, vp, vp, C.POINTER(_Rect), u32, vp, C.POINTER(OracleStats), C.c_int, vp]
+        lib.oracle_sample_texture.restype = None
+        lib.oracle_sample_texture.argtypes = [vp, u32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         lib.oracle_tonemap.restype = None
         lib.oracle_tonemap.argtypes = [vp, u32, vp, vp]
         declare_leaf_api(lib, "oracle_")
 
-    def render(self, spheres, materials, scene_data, camera, gs, rect=None, row_step=1, threads=1):
-        """-> (rgba float32 array (h, w, 4), OracleStats).  Rows skipped by row_step are left as NaN."""
+    @staticmethod
+    def _textures_struct(texture_set):
+        tex, n_tex, obj, rot = texture_set.as_ctypes()
+        t = OracleTextures(C.cast(tex, C.c_void_p), n_tex, C.cast(obj, C.c_void_p), rot.ctypes.data)
+        return t, (tex, obj, rot)
+
+    def sample_texture(self, texture_set, index, uv):
+        t, keep = self._textures_struct(texture_set)
+        uvf = (C.c_float * 2)(*[float(x) for x in uv]); out = (C.c_float * 4)()
+        self.lib.oracle_sample_texture(C.addressof(t), index, uvf, out)
+        return np.array(out[:], dtype=np.float32)
+
+    def render(self, spheres, materials, scene_data, camera, gs, rect=None, row_step=1, threads=1, textures=None):
+        """-> (rgba float32 array (h, w, 4), OracleStats).  Rows skipped by row_step are left as NaN.
+        textures: a dxrs_amd.textures.TextureSet (row N1) or None."""
         spheres = np.ascontiguousarray(spheres)
         materials = np.ascontiguousarray(materials)
         if rect is None:
@@ -86,8 +112,13 @@ class Oracle:
         r = _Rect(*rect)
         out = np.full((r.h, r.w, 4), np.nan, dtype=np.float32)
         stats = OracleStats()
-        rc = self.lib.oracle_render(spheres.ctypes.data, materials.ctypes.data, len(spheres), C.addressof(scene_data), C.addressof(camera),
-                                    C.addressof(gs), C.byref(r), row_step, out.ctypes.data, C.byref(stats), threads)
+        if textures is not None:
+            t, keep = self._textures_struct(textures)
+            rc = self.lib.oracle_render_textured(spheres.ctypes.data, materials.ctypes.data, len(spheres), C.addressof(scene_data), C.addressof(camera),
+                                                 C.addressof(gs), C.byref(r), row_step, out.ctypes.data, C.byref(stats), threads, C.addressof(t))
+        else:
+            rc = self.lib.oracle_render(spheres.ctypes.data, materials.ctypes.data, len(spheres), C.addressof(scene_data), C.addressof(camera),
+                                        C.addressof(gs), C.byref(r), row_step, out.ctypes.data, C.byref(stats), threads)
         if rc:
             raise RuntimeError(f"oracle_render failed ({rc})")
         return out, stats

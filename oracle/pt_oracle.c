@@ -630,11 +630,202 @@ static void trace_event(trace_t *tr, uint32_t s, uint32_t bnc, const hit_t *h, i
     e[13] = as_float(rng); e[14] = (float)lobe; e[15] = (float)flags;
 }
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Row N1: textured spheres.  EvaluateMaterial (Shaders/ShadingHelpers.hlsli:161-235) with Sample (:53-59), EvaluateBaseColor
+ * (:61-72), EvaluateTransmission (:74-85), PerturbNormal (:87-103), Math::CalculateTBN (Math.hlsli:17-21),
+ * HitInfo::GetFrontTangent (HitInfo.hlsli:91-94).  The mesh-derived inputs are restated for analytic spheres (DESIGN.md
+ * specs S6-S8): GeoSphere texture coordinates from the object-space normal, tangent along increasing u, level-0 bilinear
+ * wrap sampling, and a fixed-polynomial atan2.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const OracleTextures *t;
+    float unorm[256], srgb[256]; /* 8-bit code -> linear value */
+} tex_ctx;
+
+static void tex_ctx_init(tex_ctx *c, const OracleTextures *t)
+{
+    c->t = t;
+    for (int v = 0; v < 256; v++) {
+        c->unorm[v] = (float)v * (1.0f / 255.0f);
+        c->srgb[v] = oracle_from_srgb(c->unorm[v]);
+    }
+}
+
+float oracle_atan2(float y, float x)
+{
+    float ax = f_abs(x), ay = f_abs(y);
+    float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    if (!(mx > 0.0f)) return 0.0f;
+    float a = mn / mx, s = a * a;
+    float r = a * FMA(s, FMA(s, FMA(s, FMA(s, FMA(s, -0.01172120f, 0.05265332f), -0.11643287f), 0.19354346f), -0.33262347f), 0.99997726f);
+    if (ay > ax) r = 1.57079632679489661923f - r;
+    if (x < 0.0f) r = 3.14159265358979323846f - r;
+    return y < 0.0f ? -r : r;
+}
+
+void oracle_sphere_uv(const float n[3], float uv[2])
+{
+    float lon = oracle_atan2(n[0], -n[2]);
+    float lat = oracle_atan2(sqrtf(f_max(FMA(-n[1], n[1], 1.0f), 0.0f)), n[1]);
+    uv[0] = 1.0f - FMA(lon, 0.15915494309189533577f, 0.5f);
+    uv[1] = lat * 0.31830988618379067154f;
+}
+
+static v3 v_cross(v3 a, v3 b)
+{
+    return V3(FMA(a.y, b.z, -(a.z * b.y)), FMA(a.z, b.x, -(a.x * b.z)), FMA(a.x, b.y, -(a.y * b.x)));
+}
+
+static v3 quat_rotate(float qx, float qy, float qz, float qw, v3 v)
+{
+    v3 u = V3(qx, qy, qz);
+    v3 t = v_scale(v_cross(u, v), 2.0f);
+    return v_add(v_mad(qw, t, v), v_cross(u, t));
+}
+
+void oracle_quat_rotate(const float q[4], const float v[3], float out[3])
+{
+    v3 r = quat_rotate(q[0], q[1], q[2], q[3], V3(v[0], v[1], v[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+static v3 sphere_tangent(v3 n)
+{
+    float l2 = FMA(n.z, n.z, n.x * n.x);
+    if (!(l2 > 0.0f)) return V3(0, 0, 0);
+    float inv = 1.0f / sqrtf(l2);
+    return V3(n.z * inv, 0.0f, -n.x * inv);
+}
+
+void oracle_sphere_tangent(const float n[3], float t[3])
+{
+    v3 r = sphere_tangent(V3(n[0], n[1], n[2]));
+    t[0] = r.x; t[1] = r.y; t[2] = r.z;
+}
+
+static uint32_t wrap_index(int i, uint32_t n) { int m = i % (int)n; return (uint32_t)(m < 0 ? m + (int)n : m); }
+static float lerp1(float a, float b, float t) { return FMA(t, b - a, a); }
+
+static void fetch_texel(const tex_ctx *c, const PtTexture *tx, uint32_t x, uint32_t y, float out[4])
+{
+    const uint8_t *p = (const uint8_t *)tx->Pixels + 4u * ((size_t)y * tx->Width + x);
+    const float *lut = tx->Format == PT_TEXTURE_RGBA8_UNORM_SRGB ? c->srgb : c->unorm;
+    out[0] = lut[p[0]]; out[1] = lut[p[1]]; out[2] = lut[p[2]]; out[3] = c->unorm[p[3]];
+}
+
+/* SampleLevel(g_anisotropicSampler, uv, 0): level-0 bilinear, wrap */
+static void sample_bilinear(const tex_ctx *c, uint32_t index, const float uv[2], float out[4])
+{
+    const PtTexture *tx = &c->t->textures[index];
+    float u = uv[0], v = uv[1];
+    if (!(f_abs(u) < 65536.0f)) u = 0.0f;
+    if (!(f_abs(v) < 65536.0f)) v = 0.0f;
+    float x = FMA(u, (float)tx->Width, -0.5f), y = FMA(v, (float)tx->Height, -0.5f);
+    float xf = floorf(x), yf = floorf(y);
+    float fx = x - xf, fy = y - yf;
+    uint32_t x0 = wrap_index((int)xf, tx->Width), x1 = wrap_index((int)xf + 1, tx->Width);
+    uint32_t y0 = wrap_index((int)yf, tx->Height), y1 = wrap_index((int)yf + 1, tx->Height);
+    float c00[4], c10[4], c01[4], c11[4];
+    fetch_texel(c, tx, x0, y0, c00); fetch_texel(c, tx, x1, y0, c10);
+    fetch_texel(c, tx, x0, y1, c01); fetch_texel(c, tx, x1, y1, c11);
+    for (int k = 0; k < 4; k++) out[k] = lerp1(lerp1(c00[k], c10[k], fx), lerp1(c01[k], c11[k], fx), fy);
+}
+
+void oracle_sample_texture(const OracleTextures *t, uint32_t index, const float uv[2], float out[4])
+{
+    tex_ctx c;
+    tex_ctx_init(&c, t);
+    sample_bilinear(&c, index, uv, out);
+}
+
+/* PerturbNormal: Geometry::UnpackLocalNormal (MathLib, recollection) + CalculateTBN + RotateVectorInverse */
+static v3 perturb_normal(v3 N, v3 T, float sx, float sy)
+{
+    const float k = 255.0f / 127.0f;
+    float x = FMA(sx, k, -1.0f), y = FMA(sy, k, -1.0f);
+    float z = f_sqrt01(1.0f - FMA(y, y, x * x));
+    v3 Tn = v_normalize(v_sub(T, v_scale(N, v_dot(N, T))));
+    v3 B = v_cross(N, Tn);
+    return v_normalize(v_mad(x, Tn, v_mad(y, B, v_scale(N, z))));
+}
+
+void oracle_perturb_normal(const float N[3], const float T[3], float sx, float sy, float out[3])
+{
+    v3 r = perturb_normal(V3(N[0], N[1], N[2]), V3(T[0], T[1], T[2]), sx, sy);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+typedef struct {
+    v3 base, emissive_color;
+    float emissive_strength, metallic, roughness, ior, transmission;
+    v3 shadingN;
+} material_eval;
+
+/* The material of a hit: constant material, modulated by the object's texture maps (if any) at the hit's texture
+ * coordinates; shading normal perturbed by its normal map. */
+static material_eval evaluate_material(const tex_ctx *tc, const PtMaterial *m, const hit_t *h)
+{
+    material_eval e;
+    e.base = V3(m->BaseColor[0], m->BaseColor[1], m->BaseColor[2]);
+    e.emissive_color = V3(m->EmissiveColor[0], m->EmissiveColor[1], m->EmissiveColor[2]);
+    e.emissive_strength = m->EmissiveStrength;
+    e.metallic = m->Metallic; e.roughness = m->Roughness; e.ior = m->IOR; e.transmission = m->Transmission;
+    e.shadingN = h->shadingN;
+    if (!tc) return e;
+    const PtTextureMapInfo *maps = tc->t->object_textures[h->id].Maps;
+    int any = 0;
+    for (int k = 0; k < PT_TEXTURE_MAP_COUNT; k++) any |= maps[k].Descriptor != ~0u;
+    if (!any) return e;
+
+    float q[4] = { 0, 0, 0, 1 };
+    if (tc->t->rotations) memcpy(q, tc->t->rotations + 4u * (size_t)h->id, sizeof q);
+    v3 n_obj = quat_rotate(-q[0], -q[1], -q[2], q[3], h->N); /* world -> object */
+    float nn[3] = { n_obj.x, n_obj.y, n_obj.z }, uv[2], s[4];
+    oracle_sphere_uv(nn, uv);
+    v3 T = quat_rotate(q[0], q[1], q[2], q[3], sphere_tangent(n_obj));
+    if (!h->front) T = v_neg(T); /* GetFrontTangent */
+
+    if ((e.base.x > 0.0f || e.base.y > 0.0f || e.base.z > 0.0f) && maps[PT_TEXTURE_MAP_BASE_COLOR].Descriptor != ~0u) {
+        sample_bilinear(tc, maps[PT_TEXTURE_MAP_BASE_COLOR].Descriptor, uv, s);
+        e.base = V3(e.base.x * s[0], e.base.y * s[1], e.base.z * s[2]);
+    }
+    v3 emission = v_scale(e.emissive_color, e.emissive_strength);
+    if ((emission.x > 0.0f || emission.y > 0.0f || emission.z > 0.0f) && maps[PT_TEXTURE_MAP_EMISSIVE_COLOR].Descriptor != ~0u) {
+        sample_bilinear(tc, maps[PT_TEXTURE_MAP_EMISSIVE_COLOR].Descriptor, uv, s);
+        e.emissive_color = V3(e.emissive_color.x * s[0], e.emissive_color.y * s[1], e.emissive_color.z * s[2]);
+    }
+    if (maps[PT_TEXTURE_MAP_METALLIC_ROUGHNESS].Descriptor != ~0u) {
+        if (m->Metallic > 0.0f || m->Roughness > 0.0f) {
+            sample_bilinear(tc, maps[PT_TEXTURE_MAP_METALLIC_ROUGHNESS].Descriptor, uv, s);
+            e.metallic = m->Metallic * s[2];
+            e.roughness = m->Roughness * s[1];
+        }
+    } else {
+        if (m->Metallic > 0.0f && maps[PT_TEXTURE_MAP_METALLIC].Descriptor != ~0u) {
+            sample_bilinear(tc, maps[PT_TEXTURE_MAP_METALLIC].Descriptor, uv, s);
+            e.metallic = m->Metallic * s[0];
+        }
+        if (m->Roughness > 0.0f && maps[PT_TEXTURE_MAP_ROUGHNESS].Descriptor != ~0u) {
+            sample_bilinear(tc, maps[PT_TEXTURE_MAP_ROUGHNESS].Descriptor, uv, s);
+            e.roughness = m->Roughness * s[0];
+        }
+    }
+    if (e.metallic < 1.0f && m->Transmission > 0.0f && maps[PT_TEXTURE_MAP_TRANSMISSION].Descriptor != ~0u) {
+        sample_bilinear(tc, maps[PT_TEXTURE_MAP_TRANSMISSION].Descriptor, uv, s);
+        e.transmission = m->Transmission * s[0];
+    }
+    if ((T.x != 0.0f || T.y != 0.0f || T.z != 0.0f) && maps[PT_TEXTURE_MAP_NORMAL].Descriptor != ~0u) {
+        sample_bilinear(tc, maps[PT_TEXTURE_MAP_NORMAL].Descriptor, uv, s);
+        e.shadingN = perturb_normal(h->shadingN, T, s[0], s[1]);
+    }
+    return e;
+}
+
 /* Raytracing.hlsl:103-415 (DEFAULT permutation) + GBufferGeneration.hlsl:117-232 primary hit.
  * Writes rgba; returns rays cast. */
 static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_t n,
                              const PtSceneData *sd, const PtCamera *cam, const PtGraphicsSettings *gs,
-                             uint32_t px, uint32_t py, float rgba[4], uint64_t *paths_out, trace_t *tr)
+                             uint32_t px, uint32_t py, float rgba[4], uint64_t *paths_out, trace_t *tr, const tex_ctx *tc)
 {
     (void)paths_out;
     uint64_t rays = 0;
@@ -652,11 +843,13 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
         trace_event(tr, 0, 0, &primary, 0, V3(0, 0, 0), V3(1, 1, 1), rng, -1, 1);
         return rays;
     }
-    const PtMaterial *pm = &mat[primary.id];
-    v3 primary_radiance = v_scale(V3(pm->EmissiveColor[0], pm->EmissiveColor[1], pm->EmissiveColor[2]), pm->EmissiveStrength);
+    /* GBufferGeneration.hlsl:152-166: EvaluateMaterial at the primary hit (texture maps, normal map), then Initialize */
+    const material_eval pe = evaluate_material(tc, &mat[primary.id], &primary);
+    primary.shadingN = pe.shadingN;
+    v3 primary_radiance = v_scale(pe.emissive_color, pe.emissive_strength);
     bsdf_t primary_bsdf;
-    bsdf_init(&primary_bsdf, V3(pm->BaseColor[0], pm->BaseColor[1], pm->BaseColor[2]), pm->Metallic, pm->Roughness, pm->IOR,
-              pm->Metallic < 1.0f ? pm->Transmission : 0.0f, primary.front); /* :143-150 */
+    bsdf_init(&primary_bsdf, pe.base, pe.metallic, pe.roughness, pe.ior,
+              pe.metallic < 1.0f ? pe.transmission : 0.0f, primary.front); /* :143-150 */
 
     v3 radiance = V3(0, 0, 0);
     const uint32_t spp = gs->SamplesPerPixel;
@@ -684,9 +877,10 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
                 break;
             }
             if (bnc) { /* :293-305 */
-                const PtMaterial *m = &mat[hit.id];
-                emission = v_scale(V3(m->EmissiveColor[0], m->EmissiveColor[1], m->EmissiveColor[2]), m->EmissiveStrength);
-                bsdf_init(&bsdf, V3(m->BaseColor[0], m->BaseColor[1], m->BaseColor[2]), m->Metallic, m->Roughness, m->IOR, m->Transmission, hit.front);
+                const material_eval e = evaluate_material(tc, &mat[hit.id], &hit); /* :293-301 */
+                hit.shadingN = e.shadingN;
+                emission = v_scale(e.emissive_color, e.emissive_strength);
+                bsdf_init(&bsdf, e.base, e.metallic, e.roughness, e.ior, e.transmission, hit.front);
             }
             sample_radiance = v_add(sample_radiance, v_mul(T, emission)); /* :320 */
 
@@ -727,6 +921,7 @@ typedef struct {
     const PtSphere *sph; const PtMaterial *mat; uint32_t n;
     const PtSceneData *sd; const PtCamera *cam; const PtGraphicsSettings *gs;
     PtRect rect; uint32_t row_step; float *out;
+    const void *tex; /* tex_ctx */
     int tid, nthreads;
     uint64_t rays, paths;
 } job_t;
@@ -807,7 +1002,7 @@ static void *worker(void *arg)
         if ((int)(k % (uint32_t)j->nthreads) != j->tid) continue;
         for (uint32_t rx = 0; rx < j->rect.w; rx++) {
             float *px = j->out + 4 * ((size_t)ry * j->rect.w + rx);
-            j->rays += render_pixel(j->sph, j->mat, j->n, j->sd, j->cam, j->gs, j->rect.x + rx, j->rect.y + ry, px, &j->paths, NULL);
+            j->rays += render_pixel(j->sph, j->mat, j->n, j->sd, j->cam, j->gs, j->rect.x + rx, j->rect.y + ry, px, &j->paths, NULL, (const tex_ctx *)j->tex);
             j->paths += j->gs->SamplesPerPixel; /* nominal (pixel, sample) pairs */
         }
     }
@@ -824,13 +1019,39 @@ static int validate(const PtSceneData *sd, const PtGraphicsSettings *gs, uint32_
     return 0;
 }
 
+static int validate_textures(const OracleTextures *t, uint32_t n)
+{
+    if (!t || t->n_textures == 0) return 0;
+    if (!t->textures || !t->object_textures) return 6;
+    for (uint32_t i = 0; i < t->n_textures; i++)
+        if (!t->textures[i].Pixels || !t->textures[i].Width || !t->textures[i].Height || t->textures[i].Format > PT_TEXTURE_RGBA8_UNORM_SRGB) return 6;
+    for (uint32_t i = 0; i < n; i++)
+        for (int k = 0; k < PT_TEXTURE_MAP_COUNT; k++) {
+            const PtTextureMapInfo *mi = &t->object_textures[i].Maps[k];
+            if (mi->Descriptor != ~0u && (mi->Descriptor >= t->n_textures || mi->TextureCoordinateIndex != 0)) return 6;
+        }
+    return 0;
+}
+
 int oracle_render(const PtSphere *spheres, const PtMaterial *materials, uint32_t n,
                   const PtSceneData *scene, const PtCamera *camera,
                   const PtGraphicsSettings *gs, const PtRect *rect, uint32_t row_step,
                   float *out_rgba, OracleStats *stats, int threads)
 {
+    return oracle_render_textured(spheres, materials, n, scene, camera, gs, rect, row_step, out_rgba, stats, threads, NULL);
+}
+
+int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials, uint32_t n,
+                           const PtSceneData *scene, const PtCamera *camera,
+                           const PtGraphicsSettings *gs, const PtRect *rect, uint32_t row_step,
+                           float *out_rgba, OracleStats *stats, int threads, const OracleTextures *textures)
+{
     int err = validate(scene, gs, n);
     if (err) return err;
+    if ((err = validate_textures(textures, n)) != 0) return err;
+    tex_ctx tc;
+    const int textured = textures && textures->n_textures > 0;
+    if (textured) tex_ctx_init(&tc, textures);
     if (rect->x + rect->w > gs->RenderSize[0] || rect->y + rect->h > gs->RenderSize[1]) return 5;
     if (row_step == 0) row_step = 1;
     if (threads < 1) threads = 1;
@@ -841,6 +1062,7 @@ int oracle_render(const PtSphere *spheres, const PtMaterial *materials, uint32_t
         job_t *j = &jobs[t];
         j->sph = spheres; j->mat = materials; j->n = n; j->sd = scene; j->cam = camera; j->gs = gs;
         j->rect = *rect; j->row_step = row_step; j->out = out_rgba; j->tid = t; j->nthreads = threads;
+        j->tex = textured ? &tc : NULL;
     }
     if (threads == 1) worker(&jobs[0]);
     else {
@@ -864,7 +1086,7 @@ int oracle_trace_pixel(const PtSphere *spheres, const PtMaterial *materials, uin
     if (err) return err;
     trace_t tr = { events, max_events, 0 };
     float rgba[4]; uint64_t paths = 0;
-    render_pixel(spheres, materials, n, scene, camera, gs, px, py, rgba, &paths, &tr);
+    render_pixel(spheres, materials, n, scene, camera, gs, px, py, rgba, &paths, &tr, NULL);
     *n_events = tr.n_events;
     return 0;
 }

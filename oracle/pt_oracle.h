@@ -35,6 +35,26 @@ int oracle_render(const PtSphere *spheres, const PtMaterial *materials, uint32_t
                   const PtGraphicsSettings *gs, const PtRect *rect, uint32_t row_step,
                   float *out_rgba, OracleStats *stats, int threads);
 
+/* Row N1: the same render with textured spheres (EvaluateMaterial's texture branches, Shaders/ShadingHelpers.hlsli:53-103,
+ * 161-235).  `textures` may be NULL (= oracle_render). */
+typedef struct OracleTextures {
+    const PtTexture *textures;               /* decoded 8-bit RGBA images */
+    uint32_t n_textures;
+    const PtObjectTextures *object_textures; /* one TextureMapInfoArray per sphere */
+    const float *rotations;                  /* n quaternions (x, y, z, w) object -> world, or NULL = identity */
+} OracleTextures;
+int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials, uint32_t n,
+                           const PtSceneData *scene, const PtCamera *camera,
+                           const PtGraphicsSettings *gs, const PtRect *rect, uint32_t row_step,
+                           float *out_rgba, OracleStats *stats, int threads, const OracleTextures *textures);
+/* leaves of row N1 */
+float oracle_atan2(float y, float x);
+void oracle_sphere_uv(const float n[3], float uv[2]);
+void oracle_sphere_tangent(const float n[3], float t[3]);
+void oracle_quat_rotate(const float q[4], const float v[3], float out[3]);
+void oracle_sample_texture(const OracleTextures *t, uint32_t index, const float uv[2], float out[4]);
+void oracle_perturb_normal(const float N[3], const float T[3], float sx, float sy, float out[3]);
+
 /* Per-bounce trace of one pixel, for debugging parity: each event is 16 floats
  * {sample, bounce, hit_id(as float bits), t, Px,Py,Pz, Lx,Ly,Lz, Tr,Tg,Tb, rng_state(bits), lobe, flags}. */
 int oracle_trace_pixel(const PtSphere *spheres, const PtMaterial *materials, uint32_t n,

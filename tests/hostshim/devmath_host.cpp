@@ -3,6 +3,8 @@
 // with the CPU oracle without a GPU.  Not part of the product; never loaded by it.
 #include "../../directx-raytracing-spheres-demo_amd/csrc/pt_bsdf.h"
 #include "../../directx-raytracing-spheres-demo_amd/csrc/pt_post.h"
+#include "../../directx-raytracing-spheres-demo_amd/csrc/pt_texture.h"
+#include <vector>
 
 using namespace pt;
 
@@ -68,6 +70,37 @@ void dev_accumulate(float* accum, const float* rad, uint32_t n_pixels, uint32_t 
 {
     const float inv = 1.0f / (float)(frames_accumulated + 1u);
     for (uint32_t i = 0; i < 4u * n_pixels; i++) accum[i] = accumulate_value(accum[i], rad[i], inv, frames_accumulated == 0);
+}
+
+// ---- row N1 leaves
+float dev_atan2(float y, float x) { return atan2_spec(y, x); }
+void dev_sphere_uv(const float n[3], float uv[2]) { f2 r = sphere_uv(make_f3(n[0], n[1], n[2])); uv[0] = r.x; uv[1] = r.y; }
+void dev_sphere_tangent(const float n[3], float t[3]) { f3 r = sphere_tangent(make_f3(n[0], n[1], n[2])); t[0] = r.x; t[1] = r.y; t[2] = r.z; }
+void dev_quat_rotate(const float q[4], const float v[3], float out[3])
+{
+    f3 r = quat_rotate(q[0], q[1], q[2], q[3], make_f3(v[0], v[1], v[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void dev_perturb_normal(const float N[3], const float T[3], float sx, float sy, float out[3])
+{
+    f3 r = perturb_normal(make_f3(N[0], N[1], N[2]), make_f3(T[0], T[1], T[2]), sx, sy); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+// bilinear sample of an 8-bit RGBA image converted exactly as pt_set_textures converts it on upload
+void dev_sample_texture(const PtTexture* tx, const float uv[2], float out[4])
+{
+    const size_t count = (size_t)tx->Width * tx->Height;
+    std::vector<float4> texels(count);
+    const uint8_t* px = static_cast<const uint8_t*>(tx->Pixels);
+    for (size_t i = 0; i < count; i++) {
+        float c[4];
+        for (int k = 0; k < 4; k++) {
+            const float u = (float)px[4 * i + k] * (1.0f / 255.0f);
+            c[k] = (k < 3 && tx->Format == PT_TEXTURE_RGBA8_UNORM_SRGB) ? from_srgb(u) : u;
+        }
+        texels[i] = float4{ c[0], c[1], c[2], c[3] };
+    }
+    TexView tv{ texels.data(), tx->Width, tx->Height };
+    f2 q; q.x = uv[0]; q.y = uv[1];
+    sample_bilinear(tv, q, out);
 }
 
 struct DevBsdfOut {

@@ -34,3 +34,29 @@ def test_cpp_host_matches_python_path(dxrs, host, renderer, demo_exe, tmp_path, 
     img_py, st = renderer.render()
     assert f"rays {st.rays} " in res.stdout
     assert np.array_equal(img_cpp.view(np.uint32), img_py.view(np.uint32))
+
+
+def test_cpp_host_textured_demo_matches_python_path_and_oracle(dxrs, host, oracle, renderer, demo_exe, tmp_path):
+    """row N1 through the C++ mirror: MySceneDesc(seed, textured) -> Scene::Load (texture loader) -> Raytracing::SetScene ->
+    pt_set_textures; the same scene assembled in Python (host.demo_textures) renders the same bits, and both equal the oracle"""
+    w, h, bounces, spp, frame = 320, 180, 4, 1, 2
+    out = str(tmp_path / "frame_tex.f32")
+    res = subprocess.run([demo_exe, "textured", str(w), str(h), str(bounces), str(spp), str(frame), out], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    img_cpp = np.fromfile(out, dtype=np.float32).reshape(h, w, 4)
+    _, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    spheres = host.scene_at_time(0, 3.0)
+    ts = host.demo_textures(0, 3.0)
+    cam = host.camera(w, h, jitter_index=frame)
+    gs = dxrs.types.graphics_settings(w, h, frame_index=frame, bounces=bounces, spp=spp)
+    renderer.set_scene(spheres, materials, sd)
+    renderer.set_textures(ts)
+    renderer.set_camera(cam); renderer.set_constants(gs)
+    img_py, st = renderer.render()
+    renderer.set_textures(None)
+    assert f"rays {st.rays} " in res.stdout
+    assert np.array_equal(img_cpp.view(np.uint32), img_py.view(np.uint32))
+    ref, ost = oracle.render(spheres, materials, sd, cam, gs, threads=8, textures=ts)
+    assert ost.rays == st.rays and np.array_equal(ref.view(np.uint32)[..., :3], img_py.view(np.uint32)[..., :3])
+    plain, _ = oracle.render(spheres, materials, sd, cam, gs, threads=8)
+    assert not np.array_equal(plain.view(np.uint32), ref.view(np.uint32))

@@ -1,0 +1,273 @@
+"""Row N1 -- textured spheres: EvaluateMaterial's texture branches + normal mapping (Shaders/ShadingHelpers.hlsli:53-103,
+161-235) over analytic sphere UVs / tangents.  CPU: known answers for the build-defined pieces (UV convention, tangent,
+bilinear wrap sampler, sRGB decode, atan2 accuracy), and the product's device header (csrc/pt_texture.h compiled as host
+C++) against the oracle bit for bit.  GPU: whole frames of textured scenes through the C-ABI against the oracle, bit-exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle.binding import declare_leaf_api
+from util import count_mismatch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PF = C.POINTER(C.c_float)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    lib = C.CDLL(os.path.join(HERE, "hostshim", "libdevmath_host.so"))
+    declare_leaf_api(lib, "dev_")
+    lib.dev_sample_texture.restype = None
+    lib.dev_sample_texture.argtypes = [C.c_void_p, PF, PF]
+    return lib
+
+
+def fa(*v):
+    return (C.c_float * len(v))(*[float(x) for x in v])
+
+
+def call3(fn, *args, n_out=3):
+    out = (C.c_float * n_out)()
+    fn(*args, out)
+    return np.array(out[:], dtype=np.float32)
+
+
+def unit(rng, n):
+    v = rng.normal(size=(n, 3))
+    return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+
+def bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_atan2_accuracy_and_parity(oracle, dev):
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.normal(size=4000), [0, 0, 1, -1, 0, -0.0, 1e-30, 1e30]]).astype(np.float32)
+    ys = np.concatenate([rng.normal(size=4000), [0, 1, 0, 0, -1, 0.0, 1e30, 1e-30]]).astype(np.float32)
+    got = np.array([oracle.lib.oracle_atan2(float(y), float(x)) for x, y in zip(xs, ys)], dtype=np.float32)
+    dv = np.array([dev.dev_atan2(float(y), float(x)) for x, y in zip(xs, ys)], dtype=np.float32)
+    assert np.array_equal(bits(got), bits(dv))
+    ref = np.arctan2(ys.astype(np.float64), xs.astype(np.float64))
+    err = np.abs(got - ref); err = np.minimum(err, 2 * np.pi - err)
+    err[(xs == 0) & (ys == 0)] = 0  # atan2(0, +-0) is defined as 0 here
+    assert err.max() < 3e-5  # 1e-2 texel on a 2048-wide map
+    assert oracle.lib.oracle_atan2(0.0, 0.0) == 0.0 and abs(oracle.lib.oracle_atan2(0.0, -1.0) - np.pi) < 1e-6
+
+
+def test_sphere_uv_convention_and_parity(oracle, dev):
+    uv = lambda n: call3(oracle.lib.oracle_sphere_uv, fa(*n), n_out=2)
+    # GeoSphere convention: longitude = atan2(n.x, -n.z), uv = (1 - (lon / 2pi + 0.5), acos(n.y) / pi)
+    assert np.allclose(uv((0, 0, -1)), (0.5, 0.5), atol=2e-5)
+    assert np.allclose(uv((1, 0, 0)), (0.25, 0.5), atol=2e-5)
+    assert np.allclose(uv((-1, 0, 0)), (0.75, 0.5), atol=2e-5)
+    assert abs(uv((0, 1, 0))[1]) < 1e-6 and abs(uv((0, -1, 0))[1] - 1.0) < 1e-6
+    rng = np.random.default_rng(1)
+    for n in unit(rng, 3000):
+        a, b = uv(n), call3(dev.dev_sphere_uv, fa(*n), n_out=2)
+        assert np.array_equal(bits(a), bits(b))
+        lon = np.arctan2(float(n[0]), -float(n[2]))
+        assert abs(a[0] - (1 - (lon / (2 * np.pi) + 0.5))) < 2e-5 and abs(a[1] - np.arccos(np.clip(float(n[1]), -1, 1)) / np.pi) < 2e-5
+        assert 0.0 <= a[0] <= 1.0 and 0.0 <= a[1] <= 1.0
+
+
+def test_tangent_follows_increasing_u(oracle, dev):
+    rng = np.random.default_rng(2)
+    assert np.array_equal(call3(oracle.lib.oracle_sphere_tangent, fa(0, 1, 0)), [0, 0, 0])  # poles: no tangent -> no normal mapping
+    for n in unit(rng, 500):
+        t = call3(oracle.lib.oracle_sphere_tangent, fa(*n))
+        assert np.array_equal(bits(t), bits(call3(dev.dev_sphere_tangent, fa(*n))))
+        assert abs(np.dot(t, n)) < 1e-6 and abs(np.linalg.norm(t) - 1) < 1e-6
+        if abs(n[1]) < 0.95:
+            # moving along +t increases u (away from the u = 0 / 1 seam)
+            u0 = call3(oracle.lib.oracle_sphere_uv, fa(*n), n_out=2)[0]
+            m = n + 1e-3 * t; m /= np.linalg.norm(m)
+            u1 = call3(oracle.lib.oracle_sphere_uv, fa(*m), n_out=2)[0]
+            if 0.05 < u0 < 0.95:
+                assert u1 > u0
+
+
+def test_quaternion_rotation(oracle, dev, dxrs):
+    from dxrs_amd.textures import quaternion_axis_angle
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        axis, ang, v = unit(rng, 1)[0], rng.uniform(-np.pi, np.pi), rng.normal(size=3).astype(np.float32)
+        q = quaternion_axis_angle(axis, ang)
+        a = call3(oracle.lib.oracle_quat_rotate, fa(*q), fa(*v))
+        assert np.array_equal(bits(a), bits(call3(dev.dev_quat_rotate, fa(*q), fa(*v))))
+        # Rodrigues
+        k = axis.astype(np.float64); vv = v.astype(np.float64)
+        ref = vv * np.cos(ang) + np.cross(k, vv) * np.sin(ang) + k * np.dot(k, vv) * (1 - np.cos(ang))
+        assert np.allclose(a, ref, atol=2e-6 * max(1.0, np.abs(vv).max()))
+        # conjugate undoes it
+        back = call3(oracle.lib.oracle_quat_rotate, fa(-q[0], -q[1], -q[2], q[3]), fa(*a))
+        assert np.allclose(back, v, atol=3e-6 * max(1.0, np.abs(vv).max()))
+
+
+def test_bilinear_sampler(oracle, dev, dxrs):
+    from dxrs_amd.textures import TextureSet
+    rng = np.random.default_rng(4)
+    ts = TextureSet(1)
+    img = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    lin, srgb = ts.add_image(img), ts.add_image(img, srgb=True)
+    # texel centres return the texel exactly; sRGB decodes colour (not alpha) through FromSrgb
+    for (x, y) in ((0, 0), (6, 4), (3, 2)):
+        uv = ((x + 0.5) / 7, (y + 0.5) / 5)
+        assert np.allclose(oracle.sample_texture(ts, lin, uv), img[y, x].astype(np.float64) / 255, atol=1e-6)
+        s = oracle.sample_texture(ts, srgb, uv)
+        want = [oracle.lib.oracle_from_srgb(float(np.float32(v) * np.float32(1 / 255))) for v in img[y, x, :3]]
+        assert np.allclose(s[:3], want, rtol=0, atol=1e-6) and abs(s[3] - img[y, x, 3] / 255) < 1e-6
+    # halfway between two texels = their mean; wrap addressing across both edges
+    a = oracle.sample_texture(ts, lin, (1.0 / 7, 0.5 / 5))
+    assert np.allclose(a, (img[0, 0].astype(np.float64) + img[0, 1]) / 2 / 255, atol=1e-6)
+    w = oracle.sample_texture(ts, lin, (0.0, 0.5 / 5))
+    assert np.allclose(w, (img[0, 6].astype(np.float64) + img[0, 0]) / 2 / 255, atol=1e-6)
+    assert np.allclose(oracle.sample_texture(ts, lin, (0.3, 0.7)), oracle.sample_texture(ts, lin, (3.3, -1.3)), atol=2e-5)
+    # device header == oracle on arbitrary coordinates, incl. out-of-range / non-finite ones
+    tex, n_tex, obj, rot = ts.as_ctypes()
+    uvs = np.concatenate([rng.uniform(-3, 3, (3000, 2)), [[0, 0], [1, 1], [1e9, -1e9], [np.nan, 0.5], [np.inf, -np.inf], [65535.9, -65535.9]]]).astype(np.float32)
+    for idx in (lin, srgb):
+        for uv in uvs:
+            d = (C.c_float * 4)()
+            dev.dev_sample_texture(C.addressof(tex[idx]), fa(*uv), d)
+            assert np.array_equal(bits(oracle.sample_texture(ts, idx, uv)), bits(d[:]))
+
+
+def test_perturb_normal(oracle, dev):
+    rng = np.random.default_rng(5)
+    for n in unit(rng, 400):
+        t = call3(oracle.lib.oracle_sphere_tangent, fa(*n))
+        if not t.any():
+            continue
+        sx, sy = rng.random(2)
+        a = call3(oracle.lib.oracle_perturb_normal, fa(*n), fa(*t), C.c_float(sx), C.c_float(sy))
+        b = call3(dev.dev_perturb_normal, fa(*n), fa(*t), C.c_float(sx), C.c_float(sy))
+        assert np.array_equal(bits(a), bits(b)) and abs(np.linalg.norm(a) - 1) < 1e-6
+        # the "flat" code 127/255 decodes to (0, 0, 1): the normal stays where it was
+        flat = call3(oracle.lib.oracle_perturb_normal, fa(*n), fa(*t), C.c_float(127 / 255), C.c_float(127 / 255))
+        assert np.allclose(flat, n, atol=1e-6)
+        # a positive x tilts the normal towards the tangent
+        tilt = call3(oracle.lib.oracle_perturb_normal, fa(*n), fa(*t), C.c_float(200 / 255), C.c_float(127 / 255))
+        assert np.dot(tilt, t) > 0.3
+
+
+def make_textured_scene(dxrs, rng, n, style):
+    """random spheres with every kind of texture map attached; returns (spheres, materials, TextureSet)"""
+    from dxrs_amd import textures as T
+    t = dxrs.types
+    s = np.zeros(n, dtype=dxrs.SPHERE_DTYPE)
+    s["cx"], s["cy"], s["cz"] = rng.uniform(-5, 5, n), rng.uniform(-3, 3, n), rng.uniform(-6, 4, n)
+    s["r"] = rng.uniform(0.4, 2.0, n)
+    if style == 1:
+        s[0] = (0, -1001.5, 0, 1000.0)
+    m = t.default_material(n)
+    m["BaseColor"][:, :3] = rng.uniform(0.3, 1.0, (n, 3))
+    m["Metallic"] = rng.choice([0.0, 1.0, 0.6], n)
+    m["Roughness"] = rng.choice([0.0, 1.0, 0.3, 0.7], n)
+    m["Transmission"] = rng.choice([0.0, 1.0, 0.5], n, p=[0.6, 0.2, 0.2])
+    m["IOR"] = rng.choice([1.5, 1.33, 2.0], n)
+    emit = rng.random(n) < 0.2
+    m["EmissiveStrength"][emit] = rng.uniform(1, 10, emit.sum())
+    m["EmissiveColor"][emit] = rng.random((emit.sum(), 3))
+    ts = T.TextureSet(n)
+    imgs = {
+        "albedo": ts.add_image(T.planet_albedo(64, 32, int(rng.integers(1 << 30))), srgb=True),
+        "checker": ts.add_image(T.checker(37, 23, cells=6), srgb=False),
+        "noise": ts.add_image((T.value_noise(48, 48, int(rng.integers(1 << 30))) * 255).astype(np.uint8)),
+        "rgba": ts.add_image(rng.integers(0, 256, (9, 13, 4), dtype=np.uint8), srgb=True),
+        "normal": ts.add_image(T.normal_map_from_height(T.value_noise(64, 32, int(rng.integers(1 << 30))), strength=6.0)),
+        "one": ts.add_image(np.full((1, 1, 4), 255, np.uint8)),
+    }
+    keys = list(imgs)
+    for i in range(n):
+        if rng.random() < 0.15:
+            continue  # untextured sphere among textured ones
+        for k in range(t.TEXTURE_MAP_COUNT):
+            if rng.random() < 0.45:
+                name = "normal" if k == t.TEXTURE_MAP_NORMAL else keys[int(rng.integers(0, len(keys)))]
+                ts.assign(i, k, imgs[name])
+        ts.set_rotation(i, np.append(rng.normal(size=3), rng.normal()))
+    return s, m, ts
+
+
+def test_oracle_identity_textures_change_nothing(dxrs, host, oracle):
+    """all-white textures on every modulated input: the frame is bit-identical to the untextured one; a mid-grey base
+    colour map darkens it"""
+    from dxrs_amd import textures as T
+    t = dxrs.types
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_SMALL, seed=0)
+    w, h = 64, 48
+    cam, gs = host.camera(w, h), t.graphics_settings(w, h, bounces=3)
+    ts = T.TextureSet(len(spheres))
+    one = ts.add_image(np.full((2, 2, 4), 255, np.uint8), srgb=True)
+    for i in range(len(spheres)):
+        for k in (t.TEXTURE_MAP_BASE_COLOR, t.TEXTURE_MAP_EMISSIVE_COLOR, t.TEXTURE_MAP_METALLIC, t.TEXTURE_MAP_ROUGHNESS, t.TEXTURE_MAP_TRANSMISSION):
+            ts.assign(i, k, one)
+    ref, st = oracle.render(spheres, materials, sd, cam, gs, threads=4)
+    img, st2 = oracle.render(spheres, materials, sd, cam, gs, threads=4, textures=ts)
+    assert np.array_equal(bits(img), bits(ref)) and st.rays == st2.rays
+    grey = ts.add_image(np.full((2, 2, 4), 128, np.uint8))
+    for i in range(len(spheres)):
+        ts.assign(i, t.TEXTURE_MAP_BASE_COLOR, grey)
+    dark, _ = oracle.render(spheres, materials, sd, cam, gs, threads=4, textures=ts)
+    assert dark[..., :3].mean() < 0.9 * ref[..., :3].mean()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_gpu_textured_scene_matches_oracle(dxrs, host, oracle, renderer, seed):
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([3, 8, 20, 500]))  # 500: BVH in global memory
+    spheres, materials, ts = make_textured_scene(dxrs, rng, n, seed % 2)
+    sd = host.scene(dxrs.host.SCENE_SMALL)[2]
+    w, h = int(rng.choice([64, 97])), int(rng.choice([48, 61]))
+    pos = (0.0, 0.5, -12.0) if seed % 3 else (0.2, 0.1, 0.0)
+    cam = host.camera(w, h, position=pos, jitter_index=seed)
+    gs = dxrs.types.graphics_settings(w, h, frame_index=seed, bounces=int(rng.choice([0, 2, 6])), spp=int(rng.choice([1, 3])), rr=bool(seed % 2))
+    renderer.set_scene(spheres, materials, sd)
+    renderer.set_textures(ts)
+    renderer.set_camera(cam); renderer.set_constants(gs)
+    img, st = renderer.render()
+    ref, ost = oracle.render(spheres, materials, sd, cam, gs, threads=8, textures=ts)
+    assert st.rays == ost.rays
+    assert count_mismatch(img, ref) == 0
+    # textures matter ...
+    plain, _ = oracle.render(spheres, materials, sd, cam, gs, threads=8)
+    if n >= 8 and gs.Bounces >= 2:
+        assert not np.array_equal(bits(plain), bits(ref))
+    # ... and removing them restores the untextured frame
+    renderer.set_textures(None)
+    img2, _ = renderer.render()
+    assert count_mismatch(img2, plain) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_texture_api_errors_and_rotation_update(dxrs, host, oracle, renderer):
+    from dxrs_amd import textures as T
+    t = dxrs.types
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_SMALL, seed=0)
+    n = len(spheres)
+    renderer.set_scene(spheres, materials, sd)
+    with pytest.raises(RuntimeError):
+        renderer.update_rotations(np.tile([0, 0, 0, 1], (n, 1)))  # no textures yet
+    ts = T.TextureSet(n)
+    a = ts.add_image(T.planet_albedo(128, 64, 5), srgb=True)
+    ts.assign(1, t.TEXTURE_MAP_BASE_COLOR, 7)  # out of range
+    with pytest.raises(RuntimeError):
+        renderer.set_textures(ts)
+    ts.assign(1, t.TEXTURE_MAP_BASE_COLOR, a)
+    renderer.set_textures(ts)
+    w, h = 160, 120
+    cam, gs = host.camera(w, h), t.graphics_settings(w, h, bounces=2)
+    renderer.set_camera(cam); renderer.set_constants(gs)
+    for ang in (0.0, 1.0, 2.5):  # the textured sphere spins about +y (Earth, Source/MyScene.ixx:289)
+        ts.set_rotation(1, T.quaternion_axis_angle((0, 1, 0), ang))
+        renderer.update_rotations(ts.rotations)
+        img, _ = renderer.render()
+        ref, _ = oracle.render(spheres, materials, sd, cam, gs, threads=8, textures=ts)
+        assert count_mismatch(img, ref) == 0
+    with pytest.raises(RuntimeError):
+        renderer.update_rotations(ts.rotations[:3])
+    renderer.set_textures(None)

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Render the demo scene on the GPU and write a tone-mapped PNG (viewer convenience; the tone map -- Reinhard + gamma 2.2 in
-numpy -- is NOT part of the measured path, the product's output is the fp32 HDR radiance buffer).
+"""Render the demo scene on the GPU and write a PNG through the product's own display path: N frames of the path tracer
+with jittered cameras -> pt_accumulate (running mean) -> pt_tonemap (ACES filmic + sRGB, the reference's SDR default) ->
+R8G8B8A8.  Viewer convenience; the measured output of the hot path is the fp32 HDR radiance buffer.
 
-    python tools/render_png.py out.png [--width 1280 --height 720 --spp 64 --bounces 8 --time 0.0]"""
+    python tools/render_png.py out.png [--width 1280 --height 720 --spp 8 --frames 16 --bounces 8 --time 0.0 --textures
+                                        --texture-dir /path/to/Assets/Textures]"""
 import argparse
 import os
 import sys
@@ -10,6 +12,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402  (device buffers only)
 import dxrs_amd_loader  # noqa: E402,F401
 import dxrs_amd  # noqa: E402
 
@@ -19,25 +22,53 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
-    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--spp", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=16, help="jittered frames accumulated by pt_accumulate")
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--time", type=float, default=0.0, help="simulation time of the closed-form motion")
+    ap.add_argument("--textures", action="store_true", help="textured Alien-Metal / Moon / Earth (procedural stand-ins)")
+    ap.add_argument("--texture-dir", default=None, help="directory with the reference's Assets/Textures files: use the real images")
+    ap.add_argument("--operator", choices=["saturate", "reinhard", "aces"], default="aces")
+    ap.add_argument("--exposure", type=float, default=0.0, help="stops")
     args = ap.parse_args()
     from PIL import Image
 
+    t = dxrs_amd.types
     host = dxrs_amd.load_host()
     spheres, materials, sd = host.scene(dxrs_amd.host.SCENE_DEMO, seed=0)
     if args.time:
         spheres = host.scene_at_time(0, args.time)
-    r = dxrs_amd.Renderer()
+    torch.cuda.init()
+    stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
+    r = dxrs_amd.Renderer(stream=stream.cuda_stream)
     r.set_scene(spheres, materials, sd)
-    r.set_camera(host.camera(args.width, args.height, jitter=False))
-    r.set_constants(dxrs_amd.types.graphics_settings(args.width, args.height, bounces=args.bounces, spp=args.spp))
-    img, st = r.render()
-    print(f"{st.rays} rays in {st.ms_total:.2f} ms ({st.rays / st.ms_total / 1e3:.0f} Mrays/s)")
-    x = np.clip(img[..., :3], 0, None)
-    x = np.clip(x / (1 + x), 0, 1) ** (1 / 2.2)
-    Image.fromarray((x * 255 + 0.5).astype(np.uint8)).save(args.out)
+    if args.textures or args.texture_dir:
+        ts = host.demo_textures(0, args.time)
+        if args.texture_dir:  # replace the stand-ins by decoded files, same slots (order: MyScene.ixx:161-166, 285-295)
+            from dxrs_amd.textures import load_image
+            names = ["Alien-Metal_Albedo.png", "Alien-Metal_Metallic.png", "Alien-Metal_Roughness.png", "Alien-Metal_Normal.png",
+                     "Moon_BaseColor.jpg", "Moon_Normal.jpg", "Earth_BaseColor.jpg", "Earth_Normal.jpg"]
+            for i, name in enumerate(names):
+                ts.images[i] = (np.ascontiguousarray(load_image(os.path.join(args.texture_dir, name))), ts.images[i][1])
+        r.set_textures(ts)
+    w, h, n = args.width, args.height, args.width * args.height
+    gs = t.graphics_settings(w, h, bounces=args.bounces, spp=args.spp)
+    frame = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    accum = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    ldr = torch.empty(n, dtype=torch.int32, device="cuda")
+    for k in range(args.frames):
+        gs.FrameIndex = k
+        r.set_camera(host.camera(w, h, jitter_index=k, jitter_count=max(args.frames, 8)))
+        r.set_constants(gs)
+        r.render_device(frame.data_ptr())
+        r.accumulate(accum.data_ptr(), frame.data_ptr(), n, k)
+    op = {"saturate": t.TONE_SATURATE, "reinhard": t.TONE_REINHARD, "aces": t.TONE_ACES_FILMIC}[args.operator]
+    r.tonemap(accum.data_ptr(), n, t.tonemap_params(op, t.TRANSFER_SRGB, args.exposure), ldr.data_ptr())
+    r.synchronize()
+    rgba = ldr.cpu().numpy().view(np.uint8).reshape(h, w, 4)
+    Image.fromarray(rgba[..., :3]).save(args.out)
+    tot = r.totals()
+    print(f"{args.frames} frames x {args.spp} spp, {tot.rays} rays -> {args.out}")
     r.close()
 
 
