@@ -776,7 +776,7 @@ PtStatus pt_refit_accel(PtContext* c)
     if (!c->accel_valid || !L.scene_private) return fail(c, PT_ERR_STATE, "pt_refit_accel: call pt_update_spheres first");
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, lbvh_gpu_refit(c->gpu_builder, L.d_sph, c->n, reinterpret_cast<PtBvhNode*>(L.d_nodes), L.d_sph_sorted, c->d_sorted_id,
-                             L.d_refit_flags, L.d_refit_hdr, L.stream));
+                             L.d_refit_flags, L.d_refit_hdr, c->depth, L.stream));
     return PT_OK;
 }
 

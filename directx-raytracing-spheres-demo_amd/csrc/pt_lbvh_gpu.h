@@ -31,6 +31,6 @@ hipError_t lbvh_gpu_build(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode
 // copy and recompute every box bottom-up.  Asynchronous on `stream`; flags (n words) and hdr (16 words) are scratch the
 // caller owns (one set per stream that may refit concurrently).
 hipError_t lbvh_gpu_refit(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode* d_nodes, float4* d_sorted, const uint32_t* d_sorted_id,
-                          uint32_t* d_flags, uint32_t* d_hdr, hipStream_t stream);
+                          uint32_t* d_flags, uint32_t* d_hdr, uint32_t depth, hipStream_t stream);
 
 }  // namespace pt

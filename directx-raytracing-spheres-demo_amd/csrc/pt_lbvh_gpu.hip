@@ -1,5 +1,5 @@
 // pt_lbvh_gpu.hip -- device LBVH builder: bounds -> 30-bit Morton keys -> radix sort (hipCUB / rocPRIM) -> Karras 2012
-// radix tree -> bottom-up AABBs -> depth.  Produces exactly the tree of the host builder (pt_lbvh.cpp): every floating
+// radix tree -> depth -> bottom-up AABBs in `depth` communication-free passes.  Produces exactly the tree of the host builder (pt_lbvh.cpp): every floating
 // point step is the same individually rounded fp32 operation, min/max are exact, and the keys are unique.
 // Replaces Scene::CreateAccelerationStructures (Source/Scene.ixx:225-284), which the reference re-runs every frame while
 // the physics is live (Source/App.cpp:605-608).
@@ -42,33 +42,44 @@ __global__ void init_header_kernel(uint32_t* hdr)
     if (i == 12) hdr[12] = 0u;
 }
 
-__global__ void bounds_kernel(const float4* __restrict__ sph, uint32_t n, uint32_t* __restrict__ hdr)
+// Scene bounds.  Per-wave shuffle reduction, then per-block through LDS: 12 atomics per BLOCK on the 12 header words (one set
+// per wave -- 196 K same-address atomics at 2^20 spheres -- cost 2.2 ms; this costs ~10 us).
+__global__ __launch_bounds__(256) void bounds_kernel(const float4* __restrict__ sph, uint32_t n, uint32_t* __restrict__ hdr)
 {
-    float cmin[3] = { INFINITY, INFINITY, INFINITY }, cmax[3] = { -INFINITY, -INFINITY, -INFINITY };
-    float bmin[3] = { INFINITY, INFINITY, INFINITY }, bmax[3] = { -INFINITY, -INFINITY, -INFINITY };
+    __shared__ float s_red[4][12];
+    float v[12];  // cmin[3], cmax[3], bmin[3], bmax[3]
+#pragma unroll
+    for (int a = 0; a < 3; a++) { v[a] = INFINITY; v[3 + a] = -INFINITY; v[6 + a] = INFINITY; v[9 + a] = -INFINITY; }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 s = sph[i];
         const float c[3] = { s.x, s.y, s.z };
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            cmin[a] = fminf(cmin[a], c[a]); cmax[a] = fmaxf(cmax[a], c[a]);
-            bmin[a] = fminf(bmin[a], c[a] - s.w); bmax[a] = fmaxf(bmax[a], c[a] + s.w);
+            v[a] = fminf(v[a], c[a]); v[3 + a] = fmaxf(v[3 + a], c[a]);
+            v[6 + a] = fminf(v[6 + a], c[a] - s.w); v[9 + a] = fmaxf(v[9 + a], c[a] + s.w);
         }
     }
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
+    for (int k = 0; k < 12; k++) {
+        const bool is_min = (k / 3) % 2 == 0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            cmin[a] = fminf(cmin[a], __shfl_down(cmin[a], off, 64)); cmax[a] = fmaxf(cmax[a], __shfl_down(cmax[a], off, 64));
-            bmin[a] = fminf(bmin[a], __shfl_down(bmin[a], off, 64)); bmax[a] = fmaxf(bmax[a], __shfl_down(bmax[a], off, 64));
+            const float o = __shfl_down(v[k], off, 64);
+            v[k] = is_min ? fminf(v[k], o) : fmaxf(v[k], o);
         }
     }
+    const uint32_t wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63u) == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            atomicMin(&hdr[0 + a], f2ord(cmin[a])); atomicMax(&hdr[3 + a], f2ord(cmax[a]));
-            atomicMin(&hdr[6 + a], f2ord(bmin[a])); atomicMax(&hdr[9 + a], f2ord(bmax[a]));
-        }
+        for (int k = 0; k < 12; k++) s_red[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const int k = threadIdx.x;
+        const bool is_min = (k / 3) % 2 == 0;
+        float r = s_red[0][k];
+        for (uint32_t w = 1; w < (blockDim.x >> 6); w++) r = is_min ? fminf(r, s_red[w][k]) : fmaxf(r, s_red[w][k]);
+        if (is_min) atomicMin(&hdr[k], f2ord(r)); else atomicMax(&hdr[k], f2ord(r));
     }
 }
 
@@ -157,46 +168,109 @@ __global__ void hierarchy_kernel(const unsigned long long* __restrict__ keys, in
     }
 }
 
-// Bottom-up AABBs: one thread per leaf climbs; at every node the first arriver stops, the second (which then sees both
-// child boxes) continues.  Child boxes are stored in the parent (PtBvhNode layout).  Also tracks the leaf depth.
-__global__ void refit_kernel(const float4* __restrict__ sorted, int n, PtBvhNode* __restrict__ nodes, const int* __restrict__ leaf_parent,
-                             uint32_t* __restrict__ flags, const uint32_t* __restrict__ hdr_ro)
+// Bottom-up AABBs without inter-thread communication inside a launch.  A node's record holds its CHILDREN's boxes
+// (PtBvhNode layout); it can be written once both children are complete (a leaf is complete from the start; an internal
+// child is complete once ITS record is written, and its own box is the union of the two boxes stored there).
+//   level[i] = the pass in which node i was completed (0xFFFFFFFF = not yet); a child counts as complete only if its
+//   level is < the current pass, i.e. it was written by an EARLIER launch (n > 1024) or before the last barrier (n <= 1024),
+//   so a racing same-pass write is never consumed.  Passes needed = tree depth.
+// This replaces one-thread-per-leaf climbing with atomic arrival counters: the agent-scope release / acquire fences that
+// scheme needs write back and invalidate the per-XCD L2 on this GPU -- 7.2 ms at 2^20 spheres, 35 us at 441.
+__device__ __forceinline__ void leaf_box(const float4 s, float pad, float lo[3], float hi[3])
+{
+    lo[0] = s.x - s.w - pad; lo[1] = s.y - s.w - pad; lo[2] = s.z - s.w - pad;
+    hi[0] = s.x + s.w + pad; hi[1] = s.y + s.w + pad; hi[2] = s.z + s.w + pad;
+}
+
+__device__ __forceinline__ void child_box(const float4* __restrict__ sorted, const PtBvhNode* nodes, int c, float pad, float lo[3], float hi[3])
+{
+    if (c < 0) {
+        leaf_box(sorted[~c], pad, lo, hi);
+    } else {
+        const PtBvhNode* nd = &nodes[c];
+#pragma unroll
+        for (int a = 0; a < 3; a++) { lo[a] = fminf(nd->lo0[a], nd->lo1[a]); hi[a] = fmaxf(nd->hi0[a], nd->hi1[a]); }
+    }
+}
+
+__device__ __forceinline__ float refit_padding(const uint32_t* __restrict__ hdr_ro)
 {
     // padding = 2^-17 * max |coordinate| of the scene bounds (lbvh_padding in pt_lbvh.cpp)
     float smax = 0.0f;
 #pragma unroll
     for (int a = 0; a < 3; a++) smax = fmaxf(smax, fmaxf(fabsf(ord2f(hdr_ro[6 + a])), fabsf(ord2f(hdr_ro[9 + a]))));
-    const float pad = smax * 7.62939453125e-06f;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        const float4 s = sorted[k];
-        float lo[3] = { s.x - s.w - pad, s.y - s.w - pad, s.z - s.w - pad };
-        float hi[3] = { s.x + s.w + pad, s.y + s.w + pad, s.z + s.w + pad };
-        int child = ~k;
-        int p = leaf_parent[k];
-        while (p >= 0) {
-            PtBvhNode* nd = &nodes[p];
-            const bool slot0 = nd->child0 == child;
-            float* dlo = slot0 ? nd->lo0 : nd->lo1;
-            float* dhi = slot0 ? nd->hi0 : nd->hi1;
+    return smax * 7.62939453125e-06f;
+}
+
+__device__ __forceinline__ void write_node_boxes(const float4* __restrict__ sorted, PtBvhNode* nodes, int i, int c0, int c1, float pad)
+{
+    float lo[3], hi[3];
+    PtBvhNode* nd = &nodes[i];
+    child_box(sorted, nodes, c0, pad, lo, hi);
 #pragma unroll
-            for (int a = 0; a < 3; a++) { dlo[a] = lo[a]; dhi[a] = hi[a]; }
-            // release: publish this child's box before announcing arrival (agent scope; the explicit wait keeps the
-            // write-back ahead of the atomic -- see cdna_hip_programming.md Guideline 16, compiler hazard)
-            __threadfence();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (atomicAdd(&flags[p], 1u) == 0u) break;  // first to arrive: the sibling's thread continues
-            __threadfence();  // acquire: the sibling's box was written from another CU, possibly another XCD
-            const volatile float* olo = slot0 ? nd->lo1 : nd->lo0;
-            const volatile float* ohi = slot0 ? nd->hi1 : nd->hi0;
+    for (int a = 0; a < 3; a++) { nd->lo0[a] = lo[a]; nd->hi0[a] = hi[a]; }
+    child_box(sorted, nodes, c1, pad, lo, hi);
 #pragma unroll
-            for (int a = 0; a < 3; a++) {
-                lo[a] = fminf(lo[a], olo[a]);
-                hi[a] = fmaxf(hi[a], ohi[a]);
+    for (int a = 0; a < 3; a++) { nd->lo1[a] = lo[a]; nd->hi1[a] = hi[a]; }
+}
+
+constexpr int kRefitSmall = 1024;  // up to this many spheres one workgroup does every pass (barriers instead of launches)
+
+__global__ __launch_bounds__(kRefitSmall) void refit_small_kernel(const float4* __restrict__ sorted, int n, PtBvhNode* nodes,
+                                                                  uint32_t* __restrict__ hdr)
+{
+    __shared__ uint32_t s_level[kRefitSmall];
+    const float pad = refit_padding(hdr);
+    const int i = threadIdx.x;
+    const bool is_node = i < n - 1;
+    int c0 = 0, c1 = 0;
+    if (is_node) { c0 = nodes[i].child0; c1 = nodes[i].child1; }
+    s_level[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    bool done = !is_node;
+    for (uint32_t pass = 1; pass <= 64u; pass++) {
+        if (!done) {
+            const bool r0 = c0 < 0 || s_level[c0] < pass, r1 = c1 < 0 || s_level[c1] < pass;
+            if (r0 && r1) {
+                write_node_boxes(sorted, nodes, i, c0, c1, pad);
+                s_level[i] = pass;
+                done = true;
             }
-            child = p;
-            p = nd->parent;
         }
+        __syncthreads();  // the records written in this pass are visible to the whole workgroup
+        if (s_level[0] != 0xFFFFFFFFu) break;  // the root is complete (it is written once, so every thread agrees)
     }
+    if (i == 0) hdr[12] = s_level[0];  // tree depth = the pass that completed the root
+}
+
+__global__ void refit_pass_kernel(const float4* __restrict__ sorted, int n, PtBvhNode* nodes, uint32_t* level, uint32_t pass,
+                                  const uint32_t* __restrict__ hdr_ro)
+{
+    const float pad = refit_padding(hdr_ro);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n - 1; i += gridDim.x * blockDim.x) {
+        if (level[i] != 0xFFFFFFFFu) continue;
+        const int c0 = nodes[i].child0, c1 = nodes[i].child1;
+        const bool r0 = c0 < 0 || level[c0] < pass, r1 = c1 < 0 || level[c1] < pass;
+        if (!(r0 && r1)) continue;
+        write_node_boxes(sorted, nodes, i, c0, c1, pad);
+        level[i] = pass;
+    }
+}
+
+// boxes of every node record; `level` = n uint32 of scratch; depth = tree depth (passes) for n > kRefitSmall
+static hipError_t launch_refit(const float4* sorted, uint32_t n, PtBvhNode* nodes, uint32_t* level, uint32_t* hdr, uint32_t depth, hipStream_t stream)
+{
+    if (n <= 1) return hipSuccess;
+    if (n <= (uint32_t)kRefitSmall) {
+        hipLaunchKernelGGL(refit_small_kernel, dim3(1), dim3(kRefitSmall), 0, stream, sorted, (int)n, nodes, hdr);
+        return hipGetLastError();
+    }
+    hipError_t e = hipMemsetAsync(level, 0xFF, (size_t)n * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const uint32_t threads = 256, grid = (n + threads - 1) / threads < 8192u ? (n + threads - 1) / threads : 8192u;
+    for (uint32_t pass = 1; pass <= depth; pass++)
+        hipLaunchKernelGGL(refit_pass_kernel, dim3(grid), dim3(threads), 0, stream, sorted, (int)n, nodes, level, pass, hdr);
+    return hipGetLastError();
 }
 
 __global__ void depth_kernel(const PtBvhNode* __restrict__ nodes, const int* __restrict__ leaf_parent, int n, uint32_t* __restrict__ hdr)
@@ -281,22 +355,29 @@ hipError_t lbvh_gpu_build(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode
     }
     const uint32_t threads = 256;
     const uint32_t grid = (n + threads - 1) / threads < 4096u ? (n + threads - 1) / threads : 4096u;
+    const uint32_t red_grid = grid < 512u ? grid : 512u;
     LB_CK(hipEventRecord(b->e0, stream));
     hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, stream, b->hdr);
-    hipLaunchKernelGGL(bounds_kernel, dim3(grid), dim3(threads), 0, stream, d_sph, n, b->hdr);
+    hipLaunchKernelGGL(bounds_kernel, dim3(red_grid), dim3(threads), 0, stream, d_sph, n, b->hdr);
     hipLaunchKernelGGL(morton_kernel, dim3(grid), dim3(threads), 0, stream, d_sph, n, b->hdr, b->keys_in);
     size_t tmp = b->sort_tmp_bytes;
     LB_CK(hipcub::DeviceRadixSort::SortKeys(b->sort_tmp, tmp, b->keys_in, b->keys_out, (int)n, 0, 62, stream));
     hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(threads), 0, stream, d_sph, b->keys_out, n, d_sorted, d_sorted_id);
+    uint32_t hdr[kHdrWords];
     if (n > 1) {
-        LB_CK(hipMemsetAsync(b->flags, 0, (size_t)n * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(hierarchy_kernel, dim3(grid), dim3(threads), 0, stream, b->keys_out, (int)n, d_nodes, b->leaf_parent);
-        hipLaunchKernelGGL(refit_kernel, dim3(grid), dim3(threads), 0, stream, d_sorted, (int)n, d_nodes, b->leaf_parent, b->flags, b->hdr);
-        hipLaunchKernelGGL(depth_kernel, dim3(grid), dim3(threads), 0, stream, d_nodes, b->leaf_parent, (int)n, b->hdr);
+        uint32_t depth = 0;
+        if (n > (uint32_t)kRefitSmall) {
+            // the number of refit passes is the tree depth: measure it first (leaf -> root walks), one small read-back
+            hipLaunchKernelGGL(depth_kernel, dim3(grid), dim3(threads), 0, stream, d_nodes, b->leaf_parent, (int)n, b->hdr);
+            LB_CK(hipMemcpyAsync(hdr, b->hdr, sizeof hdr, hipMemcpyDeviceToHost, stream));
+            LB_CK(hipStreamSynchronize(stream));
+            depth = hdr[12];
+        }
+        LB_CK(launch_refit(d_sorted, n, d_nodes, b->flags, b->hdr, depth, stream));
     }
     LB_CK(hipGetLastError());
     LB_CK(hipEventRecord(b->e1, stream));
-    uint32_t hdr[kHdrWords];
     LB_CK(hipMemcpyAsync(hdr, b->hdr, sizeof hdr, hipMemcpyDeviceToHost, stream));
     LB_CK(hipStreamSynchronize(stream));
     float ms = 0;
@@ -314,18 +395,16 @@ hipError_t lbvh_gpu_build(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode
 }
 
 hipError_t lbvh_gpu_refit(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode* d_nodes, float4* d_sorted, const uint32_t* d_sorted_id,
-                          uint32_t* d_flags, uint32_t* d_hdr, hipStream_t stream)
+                          uint32_t* d_flags, uint32_t* d_hdr, uint32_t depth, hipStream_t stream)
 {
     if (!b || !d_sph || n == 0 || !d_sorted || !d_sorted_id || !d_flags || !d_hdr || n > b->cap) return hipErrorInvalidValue;
     const uint32_t threads = 256;
     const uint32_t grid = (n + threads - 1) / threads < 4096u ? (n + threads - 1) / threads : 4096u;
+    const uint32_t red_grid = grid < 512u ? grid : 512u;
     hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, stream, d_hdr);
-    hipLaunchKernelGGL(bounds_kernel, dim3(grid), dim3(threads), 0, stream, d_sph, n, d_hdr);  // the padding follows the new bounds
+    hipLaunchKernelGGL(bounds_kernel, dim3(red_grid), dim3(threads), 0, stream, d_sph, n, d_hdr);  // the padding follows the new bounds
     hipLaunchKernelGGL(gather_by_id_kernel, dim3(grid), dim3(threads), 0, stream, d_sph, d_sorted_id, n, d_sorted);
-    if (n > 1) {
-        LB_CK(hipMemsetAsync(d_flags, 0, (size_t)n * sizeof(uint32_t), stream));
-        hipLaunchKernelGGL(refit_kernel, dim3(grid), dim3(threads), 0, stream, d_sorted, (int)n, d_nodes, b->leaf_parent, d_flags, d_hdr);
-    }
+    LB_CK(launch_refit(d_sorted, n, d_nodes, d_flags, d_hdr, depth, stream));
     return hipGetLastError();
 }
 
