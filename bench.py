@@ -278,6 +278,19 @@ def main():
             if n1 and ms1 > 0:
                 excl = {"avg_launch_ms": ms1 / n1, "achieved": (b / n) / (ms1 / n1 * 1e-3) / 1e9}
                 excl["frac"] = excl["achieved"] / HBM_PEAK_GBS
+        # the bound that actually binds: VALU issue.  Instruction counts per launch from the committed SQ-counter pass
+        # (profiles/sq_counters.json, made by profiles/collect.sh + make_sq_counters.py); 4 cycles per wave64 VALU instruction
+        # on 256 CUs x 4 SIMDs at the measured 2.35 GHz (tools/experiments/clock.hip)
+        valu = None
+        try:
+            if pmc.get("workload") == f"{args.scene}-{w}x{h}-{args.spp}spp-{args.bounces}b" and not split and not args.textures and not tiled:
+                sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))["kernels"]
+                per_frame = sum(k["valu_insts_per_launch"] for k in sq.values())
+                bound_ms = per_frame * 4 / 1024 / 2.35e9 * 1e3
+                valu = {"wave_insts_per_frame": per_frame, "valu_bound_ms_per_frame": bound_ms, "frac_of_valu_bound": bound_ms / ms_per_step,
+                        "source": "profiles/sq_counters.json (rocprofv3 SQ_INSTS_VALU per launch, one frame in flight)"}
+        except Exception:
+            pass
         result["roofline"] = {
             "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -285,6 +298,7 @@ def main():
             "compacting_ms_per_frame": prof.ms_traverse / n_f, "shade_ms_per_frame": prof.ms_shade / n_f, "loop_ms_per_frame": prof.ms_tail / n_f,
             "ms_per_step_with_events": elapsed_ev / n_f * 1e3,
             "exclusive": excl,
+            "valu": valu,
             "sustained_gbs": (b / n_f) / (elapsed / args.steps) / 1e9,
             "note": "achieved/frac: per-launch HIP events over a second timed region of the same K steps (they agree with the rocprofv3 "
                     "kernel-trace averages of this command); with N frames in flight the launches of consecutive frames overlap and share "

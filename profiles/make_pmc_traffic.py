@@ -20,7 +20,9 @@ def per_kernel(path, counter):
         n = r["Kernel_Name"]
         if "bounce_kernel" not in n:
             continue
-        key = "bounce<loop>" if ", false, true>" in n else "bounce<wavefront>"
+        # bounce_kernel<kLds, StackT, kPrimary, kLoop, kMulti, kTex>
+        args = n[n.index("bounce_kernel<") + len("bounce_kernel<"):].split(">")[0].split(", ")
+        key = "bounce<loop>" if len(args) > 3 and args[3] == "true" else "bounce<wavefront>"
         agg[key][0] += float(r["Counter_Value"])
         agg[key][1] += 1
     return {k: (v / n, n) for k, (v, n) in agg.items()}
