@@ -230,24 +230,34 @@ def main():
         my_pixels = tot_ev.pixels / n_f
         my_secondary = (tot_ev.rays - tot_ev.pixels) / n_f
         n_wf = prof.traverse_launches // n_f  # compacting passes per frame (incl. the primary pass)
-        # DESIGN.md byte model (fused schedule): a compacting pass reads 48 B per ray of its input queue (none for the
-        # primary pass, which generates its rays), writes 48 B per ray it emits and 16 B per pixel it finishes; the
-        # looping pass reads 48 B per queued ray and writes 16 B per pixel it finishes.
         qs = queue_sizes
+        my_rays = tot_ev.rays / n_f
+        inline1 = tot_ev.rays_first_pass_inline / n_f  # bounce-1 rays the primary pass traced in registers (never queued)
         if qs and len(qs) > n_wf >= 1:
             wf_in, wf_out, loop_in = sum(qs[1:n_wf]), sum(qs[1:n_wf + 1]), qs[n_wf]
             px_wf = qs[0] - loop_in if world == 1 else my_pixels - loop_in
         else:  # no per-queue sizes (spp > 1): every secondary ray is written once and read once
             wf_in = wf_out = my_secondary; loop_in = 0; px_wf = my_pixels
-        bytes_wf = (48 * wf_in + 48 * wf_out + 16 * px_wf) * n_f
-        bytes_loop = (48 * loop_in + 16 * loop_in) * n_f
+        # (1) SURVEY 8(d) accounting -- the figure `achieved` uses: 160 B per ray (2R + 2H + R' of the wavefront formulation) +
+        #     40 B per path, times the rays traced / paths finished by the launches of the class.
+        rays_wf = my_pixels + inline1 + wf_in          # compacting passes: primaries, in-register bounce-1 rays, queued rays
+        rays_loop = max(my_rays - rays_wf, 0.0)        # everything else is traced by the looping pass
+        paths_wf, paths_loop = px_wf * args.spp, loop_in if args.spp == 1 else 0
+        survey_wf = (160 * rays_wf + 40 * paths_wf) * n_f
+        survey_loop = (160 * rays_loop + 40 * paths_loop) * n_f
+        # (2) what THIS implementation has to move (DESIGN.md byte model, fused schedule): a compacting pass reads 48 B per ray of
+        #     its input queue, writes 48 B per ray it emits and 16 B per pixel it finishes; the looping pass reads 48 B per queued
+        #     ray and writes 16 B per pixel it finishes -- rays kept in registers cost nothing.
+        impl_wf = (48 * wf_in + 48 * wf_out + 16 * px_wf) * n_f
+        impl_loop = (48 * loop_in + 16 * loop_in) * n_f
         split = prof.shade_launches > 0
+        b_impl = None
         if split:  # split schedule (BVH in global memory): traverse-type launches read o,d and write hits; see DESIGN.md
             name, b, ms, n = "traverse_kernel (+ primary_kernel)", (40 * my_secondary + 56 * qs[0] if qs else 40 * my_secondary) * n_f, prof.ms_traverse, prof.traverse_launches
         elif prof.ms_traverse >= prof.ms_tail:
-            name, b, ms, n = "bounce_kernel (compacting trace+shade passes)", bytes_wf, prof.ms_traverse, prof.traverse_launches
+            name, b, b_impl, ms, n = "bounce_kernel (primary / compacting trace+shade passes)", survey_wf, impl_wf, prof.ms_traverse, prof.traverse_launches
         else:
-            name, b, ms, n = "bounce_kernel<loop> (looping trace+shade pass)", bytes_loop, prof.ms_tail, prof.tail_launches
+            name, b, b_impl, ms, n = "bounce_kernel<loop> (looping trace+shade pass)", survey_loop, impl_loop, prof.ms_tail, prof.tail_launches
         achieved = (b / n) / (ms / n * 1e-3) / 1e9 if n and ms > 0 else 0.0
         traffic = None
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the guide prescribes)
@@ -278,6 +288,8 @@ def main():
             if n1 and ms1 > 0:
                 excl = {"avg_launch_ms": ms1 / n1, "achieved": (b / n) / (ms1 / n1 * 1e-3) / 1e9}
                 excl["frac"] = excl["achieved"] / HBM_PEAK_GBS
+                if b_impl is not None:
+                    excl["implementation_gbs"] = (b_impl / n) / (ms1 / n1 * 1e-3) / 1e9
         # the bound that actually binds: VALU issue.  Instruction counts per launch from the committed SQ-counter pass
         # (profiles/sq_counters.json, made by profiles/collect.sh + make_sq_counters.py); 4 cycles per wave64 VALU instruction
         # on 256 CUs x 4 SIMDs at the measured 2.35 GHz (tools/experiments/clock.hip)
@@ -295,15 +307,22 @@ def main():
             "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "bytes_per_launch": b / max(n, 1), "avg_launch_ms": ms / max(n, 1), "launches_per_frame": n / n_f,
+            "accounting": ("traverse-type launches of the split schedule: 40 B per secondary ray + 56 B per primary slot (DESIGN.md)" if split else
+                           "SURVEY 8(d): 160 B per ray traced + 40 B per path finished by these launches"),
+            "implementation_bytes_per_launch": None if b_impl is None else b_impl / max(n, 1),
+            "implementation_gbs": None if b_impl is None or not (n and ms > 0) else (b_impl / n) / (ms / n * 1e-3) / 1e9,
+            "rays_per_launch": None if split else (rays_wf if "loop" not in name else rays_loop) / max(n / n_f, 1),
             "compacting_ms_per_frame": prof.ms_traverse / n_f, "shade_ms_per_frame": prof.ms_shade / n_f, "loop_ms_per_frame": prof.ms_tail / n_f,
             "ms_per_step_with_events": elapsed_ev / n_f * 1e3,
             "exclusive": excl,
             "valu": valu,
             "sustained_gbs": (b / n_f) / (elapsed / args.steps) / 1e9,
-            "note": "achieved/frac: per-launch HIP events over a second timed region of the same K steps (they agree with the rocprofv3 "
+            "note": "achieved/frac: algorithmic bytes (SURVEY 8(d) per-ray / per-path figures x the rays traced and paths finished by the "
+                    "launches) / per-launch HIP events over a second timed region of the same K steps (they agree with the rocprofv3 "
                     "kernel-trace averages of this command); with N frames in flight the launches of consecutive frames overlap and share "
-                    "the GPU, so each lasts longer than when it runs alone ('exclusive': one frame at a time); 'sustained_gbs' = this "
-                    "kernel class's algorithmic bytes per frame / ms_per_step",
+                    "the GPU, so each lasts longer than when it runs alone ('exclusive': one frame at a time). 'implementation_*' = the bytes "
+                    "this fused implementation actually has to move (rays that stay in registers cost none; 'traffic' is the rocprofv3 "
+                    "measurement of it); 'valu' = the bound that really binds; 'sustained_gbs' = algorithmic bytes per frame / ms_per_step",
         }
 
     # ---- CPU baseline: the scalar oracle on this node's host cores, bounded sample of the same frame (rank 0, N = 1)

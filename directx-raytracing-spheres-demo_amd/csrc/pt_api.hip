@@ -49,7 +49,8 @@ struct Lane {
     uint32_t* h_prev_counts = nullptr;   // host-mapped: the GPU writes it when it folds a frame's counters (no copy call)
     uint32_t* d_prev_counts = nullptr;   // device address of h_prev_counts
     uint64_t prev_signature = 0;
-    unsigned long long* d_totals = nullptr;  // [0] running secondary-ray total, [1] last folded frame, [2],[3] tail counters
+    unsigned long long* d_totals = nullptr;  // [0] running secondary-ray total, [1] last folded frame, [2],[3] tail counters,
+                                             // [4] running count of in-register secondary rays of primary passes, [5] unused
     // private copy of the moving part of the scene (pt_update_spheres / pt_refit_accel): spheres, Morton-ordered spheres
     // and node boxes; null = this lane renders the context's master scene
     float4* d_sph = nullptr;
@@ -398,7 +399,9 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     const uint32_t trav_threads = traverse_threads(c->lds_scene);
     const uint32_t fused_threads = c->lds_scene ? env_u32("PT_FUSED_THREADS", 512) : 256u;
     const uint32_t loop_threads = 256u;
-    const size_t tail_after = env_u32("PT_TAIL_AFTER", split ? 3 : 1);     // wavefront bounces before the looping kernel (spp == 1)
+    // wavefront passes before the looping kernel (spp == 1).  Fused: the primary pass already traces the first bounce too
+    // (bounce_kernel kIters), so the looping kernel follows it directly: two launches per frame.
+    const size_t tail_after = env_u32("PT_TAIL_AFTER", split ? 3 : 0);
     const uint32_t tail_threshold = env_u32("PT_TAIL_THRESHOLD", 262144);  // queue size below which spp > 1 switches to it
 
     const bool timed = stats != nullptr;
@@ -599,8 +602,8 @@ PtStatus pt_create(const PtConfig* config, PtContext** out_ctx)
         bool ok = true;
         for (auto& e : L.ev_poll) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         if (!ok || hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) != hipSuccess
-            || hipMalloc(&L.d_totals, 4 * sizeof(unsigned long long)) != hipSuccess
-            || hipMemsetAsync(L.d_totals, 0, 4 * sizeof(unsigned long long), L.stream) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
+            || hipMalloc(&L.d_totals, 6 * sizeof(unsigned long long)) != hipSuccess
+            || hipMemsetAsync(L.d_totals, 0, 6 * sizeof(unsigned long long), L.stream) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
     }
     *out_ctx = c;
     return PT_OK;
@@ -1122,17 +1125,22 @@ PtStatus pt_get_totals(PtContext* c, PtStats* totals, int reset)
     if (!c) return PT_ERR_INVALID_ARG;
     if (!totals) return fail(c, PT_ERR_INVALID_ARG, "pt_get_totals: null output");
     PT_HIP(c, hipSetDevice(c->device));
-    unsigned long long secondary = 0;
+    unsigned long long secondary = 0, first_pass = 0;
     for (uint32_t i = 0; i < c->n_lanes; i++) {
         Lane& L = c->lanes[i];
-        unsigned long long s = 0;
+        unsigned long long s[5] = {};
         PT_HIP(c, flush_all_counters(L));  // fold the frames still sitting in the per-frame counters
-        PT_HIP(c, hipMemcpyAsync(&s, L.d_totals, sizeof s, hipMemcpyDeviceToHost, L.stream));
+        PT_HIP(c, hipMemcpyAsync(s, L.d_totals, sizeof s, hipMemcpyDeviceToHost, L.stream));
         PT_HIP(c, hipStreamSynchronize(L.stream));
-        secondary += s;
-        if (reset) PT_HIP(c, hipMemsetAsync(L.d_totals, 0, 2 * sizeof(unsigned long long), L.stream));
+        secondary += s[0];
+        first_pass += s[4];
+        if (reset) {
+            PT_HIP(c, hipMemsetAsync(L.d_totals, 0, 2 * sizeof(unsigned long long), L.stream));
+            PT_HIP(c, hipMemsetAsync(L.d_totals + 4, 0, sizeof(unsigned long long), L.stream));
+        }
     }
     std::memset(totals, 0, sizeof *totals);
+    totals->rays_first_pass_inline = first_pass;
     totals->rays = c->tot_pixels + secondary;
     totals->paths = c->tot_paths;
     totals->pixels = c->tot_pixels;

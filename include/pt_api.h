@@ -90,6 +90,8 @@ typedef struct PtStats {
     double ms_tail;             /* device time of the fused tail launch (0 unless profiling on) */
     uint32_t tail_launches;
     uint32_t _reserved;
+    uint64_t rays_first_pass_inline; /* pt_get_totals only: secondary rays the primary passes traced in registers (the first
+                                        bounce of a 1-spp frame never enters a queue); part of `rays` */
 } PtStats;
 
 /* BVH node as traversed on the device (DESIGN.md "LBVH layout"); exposed for structural tests. */
