@@ -172,7 +172,7 @@ def main():
     r.totals(reset=True)
     elapsed = run_steps(args.warmup, args.steps)
     tot = r.totals(reset=True)
-    queue_sizes = r.queue_sizes() if args.spp == 1 else []
+    queue_sizes = r.queue_sizes()
     # Second timed region, identical except that a HIP event pair brackets every kernel launch on the stream it runs on:
     # it provides the per-launch durations of the roofline object.  (The event records cost ~10 % of frame time at this
     # frame size, which is why `value` comes from the first region.)
@@ -242,7 +242,7 @@ def main():
         #     40 B per path, times the rays traced / paths finished by the launches of the class.
         rays_wf = my_pixels + inline1 + wf_in          # compacting passes: primaries, in-register bounce-1 rays, queued rays
         rays_loop = max(my_rays - rays_wf, 0.0)        # everything else is traced by the looping pass
-        paths_wf, paths_loop = px_wf * args.spp, loop_in if args.spp == 1 else 0
+        paths_wf, paths_loop = px_wf * args.spp, loop_in * args.spp
         survey_wf = (160 * rays_wf + 40 * paths_wf) * n_f
         survey_loop = (160 * rays_loop + 40 * paths_loop) * n_f
         # (2) what THIS implementation has to move (DESIGN.md byte model, fused schedule): a compacting pass reads 48 B per ray of

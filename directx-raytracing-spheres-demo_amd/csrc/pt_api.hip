@@ -394,11 +394,15 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     // the passes are long and uneven, and more, shorter workgroups balance better (C3: 6.77 vs 6.89 ms).
     const uint32_t trav_cap = c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", spp == 1 && c->lds_scene ? 2 : 8);
     const uint32_t shade_cap = c->num_cus * env_u32("PT_SHADE_BLOCKS_PER_CU", 16);
-    const uint32_t tail_cap = c->num_cus * env_u32("PT_TAIL_BLOCKS_PER_CU", 8);
+    // the looping pass: small queues at 1 spp (256 threads, up to 8 workgroups per CU); at spp > 1 of the fused schedule it
+    // carries the whole frame after the primary pass (every lane stays busy until its pixel has all its samples), as 2
+    // persistent 512-thread workgroups per CU (C3: 6.7 -> 4.8 ms per frame against 33 queue passes + a small looping pass)
+    const bool loop_is_main = spp > 1 && !split && !std::getenv("PT_TAIL_THRESHOLD");
+    const uint32_t tail_cap = c->num_cus * env_u32("PT_TAIL_BLOCKS_PER_CU", loop_is_main ? 2 : 8);
     auto grid_for = [](uint32_t items, uint32_t threads, uint32_t cap) { return std::max(1u, std::min((items + threads - 1) / threads, cap)); };
     const uint32_t trav_threads = traverse_threads(c->lds_scene);
     const uint32_t fused_threads = c->lds_scene ? env_u32("PT_FUSED_THREADS", 512) : 256u;
-    const uint32_t loop_threads = 256u;
+    const uint32_t loop_threads = env_u32("PT_LOOP_THREADS", loop_is_main && c->lds_scene ? 512u : 256u);
     // wavefront passes before the looping kernel (spp == 1).  Fused: the primary pass already traces the first bounce too
     // (bounce_kernel kIters), so the looping kernel follows it directly: two launches per frame.
     const size_t tail_after = env_u32("PT_TAIL_AFTER", split ? 3 : 0);
@@ -418,7 +422,9 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     // decide, after pass k has filled queue k+1, whether the looping kernel takes over (and whether anything is left)
     auto poll = [&](size_t k, bool& empty, bool& go_loop) -> PtStatus {
         empty = false;
-        if (spp > 1) {
+        if (loop_is_main) {
+            go_loop = true;  // fused, spp > 1: no queue passes at all, hence nothing to poll
+        } else if (spp > 1) {
             // Lagged polling: read back the size of queue k+1 asynchronously, but decide on the size the queue had kPollLag
             // passes ago, whose copy has long completed -- the GPU never idles waiting for the host.  Queue sizes only
             // shrink (a path emits at most one ray per pass), so a stale size is an upper bound: "was already empty" and
@@ -493,7 +499,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         }
     }
     // this frame's queue sizes reach h_prev_counts when the lane's next frame folds them (frame_counters_begin): no copy call
-    if (spp == 1) L.prev_signature = signature;
+    L.prev_signature = signature;  // (the launch-grid estimates above only use them at 1 spp; pt_get_queue_sizes reports them always)
     if (L.stream != c->stream) {
         // whatever the caller queues next on its stream (a gather, a copy, the next use of `out`) sees the finished frame
         PT_HIP(c, hipEventRecord(L.ev_done, L.stream));
