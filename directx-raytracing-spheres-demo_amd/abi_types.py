@@ -145,11 +145,12 @@ def default_material(n=1):
     return m
 
 
-def graphics_settings(width, height, frame_index=0, bounces=8, spp=1, rr=True, threshold=1e-3):
-    """GraphicsSettings with the reference defaults that carry over."""
+def graphics_settings(width, height, frame_index=0, bounces=8, spp=1, rr=True, threshold=1e-3, di=False):
+    """GraphicsSettings with the reference defaults that carry over; di = IsDIEnabled (row N4)."""
     gs = PtGraphicsSettings()
     gs.RenderSize[0], gs.RenderSize[1] = width, height
     gs.FrameIndex, gs.Bounces, gs.SamplesPerPixel = frame_index, bounces, spp
     gs.ThroughputThreshold = threshold
     gs.IsRussianRouletteEnabled = 1 if rr else 0
+    gs.IsDIEnabled = 1 if di else 0
     return gs

@@ -90,6 +90,10 @@ struct PtContext {
     float4* d_rot = nullptr;         // n
     bool has_textures = false;
 
+    // emissive spheres (row N4)
+    uint32_t* d_lights = nullptr;
+    uint32_t n_lights = 0;
+
     // accel
     float4* d_nodes = nullptr;
     float4* d_sph_sorted = nullptr;
@@ -159,12 +163,12 @@ void free_lane_scene(Lane& L)
 void free_lane_buffers(Lane& L)
 {
     for (auto& q : L.q) { free_dev(q.q0); free_dev(q.q1); free_dev(q.q2); free_dev(q.hit); }
-    free_dev(L.scratch.sample_rad); free_dev(L.scratch.radiance); free_dev(L.scratch.primary_hit);
+    free_dev(L.scratch.sample_rad); free_dev(L.scratch.radiance); free_dev(L.scratch.primary_hit); free_dev(L.scratch.di);
     L.cap_slots = 0;
     L.scratch_spp = false;
 }
 
-PtStatus ensure_buffers(PtContext* c, Lane& L, size_t n_slots, bool need_spp, bool need_hits, size_t n_counts)
+PtStatus ensure_buffers(PtContext* c, Lane& L, size_t n_slots, bool need_spp, bool need_hits, size_t n_counts, bool need_di = false)
 {
     if (n_slots > L.cap_slots || (need_hits && !L.q[0].hit)) {
         PT_HIP(c, hipStreamSynchronize(L.stream));
@@ -178,6 +182,7 @@ PtStatus ensure_buffers(PtContext* c, Lane& L, size_t n_slots, bool need_spp, bo
         PT_HIP(c, hipMalloc(&L.scratch.sample_rad, n_slots * sizeof(float4)));
         L.cap_slots = n_slots;
     }
+    if (need_di && !L.scratch.di) PT_HIP(c, hipMalloc(&L.scratch.di, L.cap_slots * sizeof(float4)));
     if (need_spp && !L.scratch_spp) {
         PT_HIP(c, hipMalloc(&L.scratch.radiance, L.cap_slots * sizeof(float4)));
         PT_HIP(c, hipMalloc(&L.scratch.primary_hit, L.cap_slots * sizeof(uint2)));
@@ -239,6 +244,7 @@ SceneView make_scene_view(const PtContext* c, const Lane* L = nullptr)
     sv.lds_scene = c->lds_scene ? 1u : 0u;
     for (int i = 0; i < 4; i++) sv.env[i] = c->sd.EnvironmentLightColor[i];
     if (c->has_textures) { sv.tex = c->d_tex; sv.tex_maps = c->d_tex_maps; sv.rot = c->d_rot; }
+    sv.lights = c->d_lights; sv.n_lights = c->n_lights;
     return sv;
 }
 
@@ -252,6 +258,7 @@ FrameParams make_frame_params(const PtContext* c)
     fp.rr_enabled = c->gs.IsRussianRouletteEnabled ? 1u : 0u;
     fp.throughput_threshold = c->gs.ThroughputThreshold;
     fp.inv_spp = 1.0f / (float)c->gs.SamplesPerPixel;
+    fp.di_enabled = (c->gs.IsDIEnabled && c->n_lights > 0) ? 1u : 0u;  // no emitters: DI is 0 everywhere, nothing to do
     return fp;
 }
 
@@ -353,7 +360,8 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         PT_HIP(c, flush_all_counters(L));
         PT_HIP(c, hipStreamSynchronize(L.stream));
     }
-    PtStatus st = ensure_buffers(c, L, pm.n_slots, spp > 1, split, wf_cap + 2);
+    const bool di = c->gs.IsDIEnabled && c->n_lights > 0;
+    PtStatus st = ensure_buffers(c, L, pm.n_slots, spp > 1, split, wf_cap + 2, di);
     if (st != PT_OK) return st;
     if (L.stream != c->stream) {
         // N frames in flight.  The caller rotates over N output buffers, so this frame may start as soon as the consumer of
@@ -393,6 +401,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     // for) amortise the 37 KB staging over ~4 batches of rays at 1080p / 1 spp (0.121 -> 0.116 ms per frame); with spp > 1
     // the passes are long and uneven, and more, shorter workgroups balance better (C3: 6.77 vs 6.89 ms).
     const uint32_t trav_cap = c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", spp == 1 && c->lds_scene ? 2 : 8);
+    const uint32_t trav_cap_wide = c->num_cus * 8u;
     const uint32_t shade_cap = c->num_cus * env_u32("PT_SHADE_BLOCKS_PER_CU", 16);
     // the looping pass: small queues at 1 spp (256 threads, up to 8 workgroups per CU); at spp > 1 of the fused schedule it
     // carries the whole frame after the primary pass (every lane stays busy until its pixel has all its samples), as 2
@@ -445,6 +454,11 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         return PT_OK;
     };
 
+    if (fp.di_enabled) {
+        // row N4: the direct-illumination estimate of every primary surface, before the bounce passes read it
+        const uint32_t di_grid = grid_for(pm.n_slots, trav_threads, trav_cap_wide);
+        PT_HIP(c, bracket(1, [&] { return launch_di(sv, pm, fp, L.scratch.di, fc.tail_rays, di_grid, L.stream); }));
+    }
     if (!split) {
         // pass 0 generates + traces the primaries and shades them into queue 1; pass k >= 1 consumes queue k
         for (size_t k = 0;; k++) {
@@ -632,7 +646,7 @@ void pt_destroy(PtContext* c)
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);
         if (L.stream && L.stream != c->stream) (void)hipStreamDestroy(L.stream);
     }
-    free_dev(c->d_sph); free_dev(c->d_mats); free_dev(c->d_nodes); free_dev(c->d_sph_sorted); free_dev(c->d_sorted_id);
+    free_dev(c->d_sph); free_dev(c->d_mats); free_dev(c->d_nodes); free_dev(c->d_sph_sorted); free_dev(c->d_sorted_id); free_dev(c->d_lights);
     free_dev(c->d_out);
     for (auto& e : c->ev_in) if (e) (void)hipEventDestroy(e);
     if (c->gpu_builder) lbvh_gpu_destroy(c->gpu_builder);
@@ -674,6 +688,19 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
         std::memcpy(&m._pad[1], &inv_ior, 4);
     }
     PT_HIP(c, hipMemcpyAsync(c->d_mats, mats.data(), (size_t)n * sizeof(PtMaterial), hipMemcpyHostToDevice, c->stream));
+    // the emitters, in id order (LightPreparation::CountLights, Source/LightPreparation.ixx:52-70: objects with any emission > 0)
+    std::vector<uint32_t> lights;
+    for (uint32_t i = 0; i < n; i++) {
+        const PtMaterial& m = materials[i];
+        if (m.EmissiveStrength * m.EmissiveColor[0] > 0.0f || m.EmissiveStrength * m.EmissiveColor[1] > 0.0f || m.EmissiveStrength * m.EmissiveColor[2] > 0.0f)
+            lights.push_back(i);
+    }
+    free_dev(c->d_lights);
+    c->n_lights = (uint32_t)lights.size();
+    if (c->n_lights) {
+        PT_HIP(c, hipMalloc(&c->d_lights, lights.size() * sizeof(uint32_t)));
+        PT_HIP(c, hipMemcpyAsync(c->d_lights, lights.data(), lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    }
     PT_HIP(c, hipStreamSynchronize(c->stream));  // caller-owned host memory may be released on return
     c->sd = *sd;
     c->scene_set = true;
@@ -806,7 +833,6 @@ PtStatus pt_set_constants(PtContext* c, const PtGraphicsSettings* gs)
         return fail(c, PT_ERR_INVALID_ARG, "pt_set_constants: RenderSize must be in [1, 65535]^2 (the RNG seed packs (x << 16) | y)");
     if (gs->SamplesPerPixel == 0 || gs->SamplesPerPixel > 65535u) return fail(c, PT_ERR_INVALID_ARG, "pt_set_constants: SamplesPerPixel must be in [1, 65535]");
     if (gs->Bounces > 250u) return fail(c, PT_ERR_INVALID_ARG, "pt_set_constants: Bounces must be <= 250");
-    if (gs->IsDIEnabled) return fail(c, PT_ERR_UNSUPPORTED, "IsDIEnabled must be 0 (ReSTIR-DI is out of scope)");
     if (gs->Denoiser) return fail(c, PT_ERR_UNSUPPORTED, "Denoiser must be 0 == Denoiser::None");
     c->gs = *gs;
     c->gs_set = true;

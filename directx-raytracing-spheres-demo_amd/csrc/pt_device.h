@@ -7,6 +7,7 @@
 
 #include "pt_bsdf.h"
 #include "pt_texture.h"
+#include "pt_light.h"
 
 namespace pt {
 
@@ -26,6 +27,7 @@ constexpr uint32_t kFlagBounceMask = 0xFFu;
 constexpr uint32_t kFlagSampleShift = 8;
 constexpr uint32_t kFlagSampleMask = 0xFFFFu;
 constexpr uint32_t kFlagDirty = 1u << 24;
+constexpr uint32_t kFlagViaTransmission = 1u << 25;  // row N4: this sample left the primary surface through the transmission lobe
 constexpr uint32_t kMissId = 0xFFFFFFFFu;
 
 // ---- scene view ------------------------------------------------------------------------------------
@@ -46,6 +48,9 @@ struct SceneView {
     const TexView* tex;         // texture table
     const uint32_t* tex_maps;   // per sphere: 7 texture indices (TextureMapType order) + 1 "has any" flag
     const float4* rot;          // per sphere: object rotation quaternion (x, y, z, w)
+    // row N4 (sphere-light direct illumination): ids of the emissive spheres, in id order
+    const uint32_t* lights;
+    uint32_t n_lights;
 };
 
 // ---- slot -> pixel mapping ---------------------------------------------------------------------------
@@ -123,7 +128,8 @@ struct FrameParams {
     CameraParams cam;
     uint32_t frame_index, bounces, spp, rr_enabled;
     float throughput_threshold;
-    float inv_spp;  // 1 / (float)spp
+    float inv_spp;        // 1 / (float)spp
+    uint32_t di_enabled;  // IsDIEnabled and the scene has emitters: Scratch::di holds this frame's estimate
 };
 
 // Per-frame device counters, double buffered by frame parity so that the first kernel of a frame can append to this
@@ -149,6 +155,7 @@ struct Scratch {
     float4* sample_rad;   // sampleRadiance of the sample in flight (valid when kFlagDirty)
     float4* radiance;     // sum over finished samples (spp > 1)
     uint2* primary_hit;   // cached primary hit for sample regeneration (spp > 1)
+    float4* di;           // row N4: direct illumination of the primary surface {rgb, valid} (IsDIEnabled only)
 };
 
 }  // namespace pt

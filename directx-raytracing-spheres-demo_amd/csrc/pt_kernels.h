@@ -35,6 +35,8 @@ hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FramePar
 hipError_t launch_unpack_tiles(const float4* packed, float4* frame, uint32_t w, uint32_t h, uint32_t ts, uint32_t tiles_x, uint32_t first0,
                                uint32_t run, uint32_t stride, uint32_t n_parts, uint64_t part_stride, hipStream_t stream);
 
+hipError_t launch_di(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, float4* di, unsigned long long* ray_counter, uint32_t grid,
+                     hipStream_t stream);
 hipError_t launch_tonemap(const float4* hdr, uint32_t* out, uint32_t n, const PtToneMapParams& p, hipStream_t stream);
 hipError_t launch_accumulate(float4* accum, const float4* rad, uint32_t n, uint32_t frames_accumulated, hipStream_t stream);
 

@@ -358,11 +358,53 @@ struct PathState {
     f3 o, d, T;
     uint32_t slot, rng, bounce, sample;
     bool dirty;  // scratch.sample_rad[slot] holds this sample's radiance so far
+    bool via_t;  // the sample left the primary surface through the transmission lobe (direct illumination does not cover it)
 };
 
 // One iteration of the bounce-loop body (Raytracing.hlsl:213-364) for a path whose ray (ps.o, ps.d) has been traced to
 // (t, id); on sample end it accumulates into the pixel, and either finishes the pixel or regenerates the next sample
 // from the cached primary hit and keeps going.  Returns true when ps holds a new ray that must be traced.
+// What a hit needs for shading: geometry frame, the material after EvaluateMaterial (textures when kTex), BSDFSample.
+struct HitMaterial {
+    HitFrame hf;
+    f3 emission, Ns;
+    Bsdf bsdf;
+};
+
+template <bool kTex>
+__device__ __forceinline__ HitMaterial hit_material(const SceneView& sv, uint32_t id, f3 o, f3 d, float t, bool primary)
+{
+    HitMaterial r;
+    const float4 sp = sv.sph[id];
+    const float4 m0 = sv.mats[id * 4 + 0], m1 = sv.mats[id * 4 + 1], m2 = sv.mats[id * 4 + 2], m3 = sv.mats[id * 4 + 3];
+    r.hf = hit_frame(o, d, t, load3(sp), sp.w);
+    f3 base = load3(m0), emissive_color = make_f3(m1.y, m1.z, m1.w);
+    float metallic = m2.x, roughness = m2.y, transmission_m = m2.w;
+    f3 Ns = r.hf.front ? r.hf.N : -r.hf.N;  // HitInfo.hlsli:60-64
+    if (kTex && sv.tex_maps) {
+        const uint4* mp = reinterpret_cast<const uint4*>(sv.tex_maps + (size_t)id * 8u);
+        const uint4 ma = mp[0], mb = mp[1];
+        if (mb.w) {  // this sphere has at least one texture map
+            const uint32_t maps[kMapCount] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z };
+            const float4 q = sv.rot[id];
+            const f3 n_obj = quat_rotate(-q.x, -q.y, -q.z, q.w, r.hf.N);  // world -> object: the conjugate rotation
+            const f2 uv = sphere_uv(n_obj);
+            f3 T = quat_rotate(q.x, q.y, q.z, q.w, sphere_tangent(n_obj));
+            if (!r.hf.front) T = -T;  // HitInfo::GetFrontTangent
+            const MaterialEval me = evaluate_material(sv.tex, maps, uv, base, m1.x, emissive_color, metallic, roughness, transmission_m, Ns, T);
+            base = me.BaseColor; emissive_color = me.EmissiveColor; metallic = me.Metallic; roughness = me.Roughness;
+            transmission_m = me.Transmission; Ns = me.Ns;
+        }
+    }
+    r.emission = emissive_color * m1.x;  // Material::GetEmission
+    r.Ns = Ns;
+    // the primary hit mirrors the G-buffer round trip: Transmission = Metallic < 1 ? Transmission : 0 (Raytracing.hlsl:148)
+    const float transmission = (primary && !(metallic < 1.0f)) ? 0.0f : transmission_m;
+    // m3.z / m3.w: dielectric F0 and 1/IOR, precomputed per material by pt_set_scene (padding words of PtMaterial)
+    r.bsdf = bsdf_init_pre(base, metallic, roughness, m2.z, m3.w, m3.z, transmission, r.hf.front);
+    return r;
+}
+
 // kMulti = false specialises for SamplesPerPixel == 1: no radiance accumulator, no primary-hit cache, no sample
 // regeneration (and with it no camera parameters live across the bounce loop).
 // kTex = true adds EvaluateMaterial's texture branches + normal mapping (row N1; csrc/pt_texture.h).  It is a template
@@ -391,32 +433,17 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
             srad = srad + ps.T * env;  // :254
             end_sample = true;
         } else {
-            const float4 sp = sv.sph[id];
-            const float4 m0 = sv.mats[id * 4 + 0], m1 = sv.mats[id * 4 + 1], m2 = sv.mats[id * 4 + 2], m3 = sv.mats[id * 4 + 3];
-            hf = hit_frame(ps.o, ps.d, t, load3(sp), sp.w);
-            f3 base = load3(m0), emissive_color = make_f3(m1.y, m1.z, m1.w);
-            float metallic = m2.x, roughness = m2.y, transmission_m = m2.w;
-            f3 Ns = hf.front ? hf.N : -hf.N;  // HitInfo.hlsli:60-64
-            if (kTex && sv.tex_maps) {
-                const uint4* mp = reinterpret_cast<const uint4*>(sv.tex_maps + (size_t)id * 8u);
-                const uint4 ma = mp[0], mb = mp[1];
-                if (mb.w) {  // this sphere has at least one texture map
-                    const uint32_t maps[kMapCount] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z };
-                    const float4 q = sv.rot[id];
-                    const f3 n_obj = quat_rotate(-q.x, -q.y, -q.z, q.w, hf.N);  // world -> object: the conjugate rotation
-                    const f2 uv = sphere_uv(n_obj);
-                    f3 T = quat_rotate(q.x, q.y, q.z, q.w, sphere_tangent(n_obj));
-                    if (!hf.front) T = -T;  // HitInfo::GetFrontTangent
-                    const MaterialEval me = evaluate_material(sv.tex, maps, uv, base, m1.x, emissive_color, metallic, roughness, transmission_m, Ns, T);
-                    base = me.BaseColor; emissive_color = me.EmissiveColor; metallic = me.Metallic; roughness = me.Roughness;
-                    transmission_m = me.Transmission; Ns = me.Ns;
-                }
-            }
-            const f3 emission = emissive_color * m1.x;  // Material::GetEmission
-            // bounce 0 mirrors the G-buffer round trip: Transmission = Metallic < 1 ? Transmission : 0 (Raytracing.hlsl:148)
-            const float transmission = (ps.bounce == 0 && !(metallic < 1.0f)) ? 0.0f : transmission_m;
-            // m3.z / m3.w: dielectric F0 and 1/IOR, precomputed per material by pt_set_scene (padding words of PtMaterial)
-            const Bsdf bsdf = bsdf_init_pre(base, metallic, roughness, m2.z, m3.w, m3.z, transmission, hf.front);
+            const HitMaterial hm = hit_material<kTex>(sv, id, ps.o, ps.d, t, ps.bounce == 0);
+            hf = hm.hf;
+            f3 emission = hm.emission;
+            const f3 Ns = hm.Ns;
+            const Bsdf& bsdf = hm.bsdf;
+            // Sphere-light direct illumination (row N4) covers what the reflective lobes of the primary surface receive from the
+            // emitters, so the emission of a first-bounce hit reached through them is dropped (Raytracing.hlsl:302).  The flag
+            // is "the pixel has a primary surface", not the reference's any(DI > 0): with a one-sample estimator DI = 0 is an
+            // ordinary sample value and conditioning on it would bias the frame upward; and a sample that left through the
+            // transmission lobe keeps its emission, because DI evaluates the reflective lobes only.
+            if (fp.di_enabled && ps.bounce == 1 && !ps.via_t) emission = make_f3(0.f, 0.f, 0.f);
             const bool t_finite = is_finite(ps.T.x) && is_finite(ps.T.y) && is_finite(ps.T.z);
             if (emission.x != 0.0f || emission.y != 0.0f || emission.z != 0.0f || !t_finite) {
                 if (ps.dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
@@ -447,6 +474,7 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
                             end_sample = true;
                         } else {
                             { const float inv_pdf = 1.0f / pdf; ps.T = ps.T * (f * inv_pdf); }  // :346
+                            if (ps.bounce == 0) ps.via_t = lobe == kLobeTransmission;
                             if (fp.rr_enabled && ps.bounce > 3) {                     // :348-356
                                 const float p = pt_max(ps.T.x, pt_max(ps.T.y, ps.T.z));
                                 if (rng_float(ps.rng) >= p) end_sample = true;
@@ -481,6 +509,7 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
             if (is_finite(total.x) && is_finite(total.y) && is_finite(total.z)) {
                 res = total * fp.inv_spp;
             }
+            if (fp.di_enabled) { const float4 di = scratch.di[slot]; res = res + load3(di); }  // radiance += DI (:381)
             out[pr.out_index] = make_float4(res.x, res.y, res.z, 1.0f);
             return false;
         }
@@ -494,6 +523,7 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
         ps.T = make_f3(1.f, 1.f, 1.f);
         ps.bounce = 0;
         ps.dirty = false;
+        ps.via_t = false;
     }
 }
 
@@ -507,12 +537,14 @@ __device__ __forceinline__ PathState load_path(const RayQueue& q, uint32_t i)
     ps.bounce = flags & kFlagBounceMask;
     ps.sample = (flags >> kFlagSampleShift) & kFlagSampleMask;
     ps.dirty = (flags & kFlagDirty) != 0;
+    ps.via_t = (flags & kFlagViaTransmission) != 0;
     return ps;
 }
 
 __device__ __forceinline__ void store_path(const RayQueue& q, uint32_t j, const PathState& ps)
 {
-    const uint32_t flags = (ps.bounce & kFlagBounceMask) | ((ps.sample & kFlagSampleMask) << kFlagSampleShift) | (ps.dirty ? kFlagDirty : 0u);
+    const uint32_t flags = (ps.bounce & kFlagBounceMask) | ((ps.sample & kFlagSampleMask) << kFlagSampleShift) | (ps.dirty ? kFlagDirty : 0u)
+                           | (ps.via_t ? kFlagViaTransmission : 0u);
     q.q0[j] = make_float4(ps.o.x, ps.o.y, ps.o.z, as_float(ps.slot));
     q.q1[j] = make_float4(ps.d.x, ps.d.y, ps.d.z, as_float(ps.rng));
     q.q2[j] = make_float4(ps.T.x, ps.T.y, ps.T.z, as_float(flags));
@@ -653,7 +685,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
             if (kPrimary) {
                 const PixelRef pr = slot_to_pixel(pm, i);
                 live = pr.valid;
-                ps.slot = i; ps.bounce = 0; ps.sample = 0; ps.dirty = false; ps.rng = 0;
+                ps.slot = i; ps.bounce = 0; ps.sample = 0; ps.dirty = false; ps.via_t = false; ps.rng = 0;
                 ps.T = make_f3(1.f, 1.f, 1.f);
                 ps.o = make_f3(0.f, 0.f, 0.f); ps.d = make_f3(0.f, 0.f, 1.f);
                 if (live) {
@@ -710,6 +742,77 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
             if (!kLoop) atomicAdd(fc.totals + 4, total);  // running count of the rays a primary pass traced in registers (statistics)
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------ direct illumination (row N4)
+// One thread per slot, before the bounce passes (the reference's RTXDI passes likewise run before Raytracing.hlsl and
+// hand it a DI texture): re-trace the primary ray, evaluate the primary surface, sample ONE emissive sphere (uniform
+// choice, uniform direction in its cone), trace the shadow ray with the ordinary closest-hit query -- the emitter must be
+// the first thing it meets -- and store  DI = Le * (f_diffuse + f_specular) cos * n_lights / pdf.
+// shade_step drops the emission of first-bounce hits reached through a reflective lobe and adds DI to the final radiance.  Own RNG stream; both rays are counted.
+template <bool kLds, typename StackT, bool kTex>
+__global__ __launch_bounds__(kTraverseThreads) void di_kernel(SceneView sv, PixelMap pm, FrameParams fp, float4* __restrict__ di,
+                                                              unsigned long long* __restrict__ ray_counter)
+{
+    extern __shared__ float4 smem[];
+    const float4* nodes = sv.nodes;
+    const float4* sph = sv.sph_sorted;
+    const uint32_t* ids = sv.sorted_id;
+    StackT* stack;
+    if (kLds) {
+        stage_scene(sv, smem);
+        nodes = smem;
+        sph = smem + sv.n_nodes * 4u;
+        ids = reinterpret_cast<const uint32_t*>(smem + sv.n_nodes * 4u + sv.n);
+        stack = reinterpret_cast<StackT*>(reinterpret_cast<char*>(smem) + scene_lds_bytes(sv.n_nodes, sv.n));
+    } else {
+        stack = reinterpret_cast<StackT*>(smem);
+    }
+    stack += threadIdx.x;
+    uint32_t my_rays = 0;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < pm.n_slots; slot += gridDim.x * blockDim.x) {
+        const PixelRef pr = slot_to_pixel(pm, slot);
+        f3 est = make_f3(0.f, 0.f, 0.f);
+        if (pr.valid) {
+            f3 o, d;
+            float tmin, tmax, t;
+            uint32_t id;
+            primary_ray(fp.cam, pr.px, pr.py, o, d, tmin, tmax);
+            closest_hit<StackT>(nodes, sph, ids, sv.n, o, d, tmin, tmax, stack, blockDim.x, t, id);
+            my_rays++;
+            if (id != kMissId) {
+                const HitMaterial hm = hit_material<kTex>(sv, id, o, d, t, true);
+                uint32_t rng = rng_init(pr.px, pr.py, fp.frame_index ^ kDiRngSalt);
+                const float u0 = rng_float(rng), u1 = rng_float(rng), u2 = rng_float(rng);
+                const uint32_t light = sv.lights[pick_light(u0, sv.n_lights)];
+                const float4 ls = sv.sph[light];
+                const LightSample s = sample_sphere_cone(hm.hf.P, load3(ls), ls.w, u1, u2);
+                const Surf surf = surf_init(hm.hf.front, hm.hf.N, hm.Ns);
+                if (light != id && s.valid && dot(surf.FrontNg, s.L) > 0.0f) {
+                    float t2;
+                    uint32_t id2;
+                    closest_hit<StackT>(nodes, sph, ids, sv.n, spawn_origin(hm.hf.P, hm.hf.N, hm.hf.offset, s.L), s.L, 0.0f, kInf, stack, blockDim.x, t2, id2);
+                    my_rays++;
+                    if (id2 == light) {
+                        const f3 V = -d;
+                        float w[3];
+                        lobe_weights(hm.bsdf, surf, V, w);
+                        const f3 f = bsdf_eval_reflective(hm.bsdf, surf, s.L, V, w);
+                        const float4 lm = sv.mats[light * 4 + 1];  // {EmissiveStrength, EmissiveColor}
+                        const f3 le = make_f3(lm.y, lm.z, lm.w) * lm.x;
+                        est = (le * f) * (s.inv_pdf * (float)sv.n_lights);
+                    }
+                }
+            }
+        }
+        if (!(est.x > 0.0f || est.y > 0.0f || est.z > 0.0f) || !is_finite(est.x) || !is_finite(est.y) || !is_finite(est.z))
+            est = make_f3(0.f, 0.f, 0.f);  // NaN / inf / negative estimates count as no light
+        di[slot] = make_float4(est.x, est.y, est.z, 0.0f);
+    }
+    unsigned long long total = my_rays;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
+    if (lane_id() == 0 && total) atomicAdd(ray_counter, total);
 }
 
 // ------------------------------------------------------------------------------------------------ test hooks
@@ -954,6 +1057,25 @@ hipError_t launch_unpack_tiles(const float4* packed, float4* frame, uint32_t w, 
     const uint32_t n = w * h;
     const uint32_t grid = (n + 255u) / 256u < 4096u ? (n + 255u) / 256u : 4096u;
     hipLaunchKernelGGL(unpack_tiles_kernel, dim3(grid), dim3(256), 0, stream, packed, frame, w, h, ts, tiles_x, first0, run, stride, n_parts, part_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_di(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, float4* di, unsigned long long* ray_counter, uint32_t grid,
+                     hipStream_t stream)
+{
+    const bool small = sv.n_nodes < 32767u;
+    const uint32_t threads = traverse_threads(sv.lds_scene != 0);
+    const uint32_t lds = traverse_lds_bytes(sv, small ? 2u : 4u);
+#define PT_DI2(L, T, X)                                                                                                     \
+    do {                                                                                                                    \
+        if (lds > 65536u) (void)hipFuncSetAttribute((const void*)di_kernel<L, T, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((di_kernel<L, T, X>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, di, ray_counter);       \
+    } while (0)
+#define PT_DI(L, T) do { if (sv.tex_maps) PT_DI2(L, T, true); else PT_DI2(L, T, false); } while (0)
+    if (sv.lds_scene) { if (small) PT_DI(true, uint16_t); else PT_DI(true, uint32_t); }
+    else { if (small) PT_DI(false, uint16_t); else PT_DI(false, uint32_t); }
+#undef PT_DI
+#undef PT_DI2
     return hipGetLastError();
 }
 

@@ -119,6 +119,10 @@ PtStatus pt_build_accel(PtContext *ctx, PtAccelInfo *info);
 PtStatus pt_update_spheres(PtContext *ctx, const PtSphere *spheres, uint32_t n);
 PtStatus pt_refit_accel(PtContext *ctx);
 PtStatus pt_set_camera(PtContext *ctx, const PtCamera *camera);
+/* Raytracing::SetConstants.  Denoiser must be 0 (Denoiser::None) and IsShaderExecutionReorderingEnabled is ignored.
+ * IsDIEnabled = 1 (row N4) adds the sphere-light direct-illumination pass, the build's stand-in for the RTXDI passes
+ * whose DI texture Raytracing.hlsl:150-163 reads: one emitter / one cone direction per pixel before the bounce passes,
+ * the emission of first-bounce hits reached through a reflective lobe dropped (:302), DI added to the radiance (:381). */
 PtStatus pt_set_constants(PtContext *ctx, const PtGraphicsSettings *settings);
 
 /* Render rect (NULL = whole RenderSize) of the frame described by the current constants/camera.

@@ -91,7 +91,7 @@ typedef struct PtGraphicsSettings {
     float ThroughputThreshold;                   /* 20: reference default 1e-3 (Raytracing.ixx:33) */
     uint32_t IsRussianRouletteEnabled;           /* 24 */
     uint32_t IsShaderExecutionReorderingEnabled; /* 28: ignored (NV SER has no meaning here) */
-    uint32_t IsDIEnabled;                        /* 32: must be 0 (ReSTIR-DI dropped) */
+    uint32_t IsDIEnabled;                        /* 32: 1 = sphere-light direct illumination of the primary surface (row N4, a stand-in for ReSTIR-DI) */
     uint32_t Denoiser;                           /* 36: must be 0 == Denoiser::None */
     uint32_t _pad0[2];                           /* 40 */
     uint32_t SHARC_Capacity;                     /* 48: SHARC block ignored (dropped) */

@@ -60,6 +60,7 @@ def declare_leaf_api(lib, prefix):
     fn("spawn_origin", None, [pf, pf, f, pf, pf])
     fn("primary_ray", None, [vp, u32, u32, u32, u32, pf, pf, pf, pf])
     fn("bsdf_step", None, [vp, C.c_int, pf, pf, pf, C.POINTER(OracleBsdfOut)])
+    fn("sample_sphere_cone", C.c_int, [pf, pf, f, f, f, pf, pf])
     fn("atan2", f, [f, f])
     fn("sphere_uv", None, [pf, pf])
     fn("sphere_tangent", None, [pf, pf])

@@ -821,11 +821,44 @@ static material_eval evaluate_material(const tex_ctx *tc, const PtMaterial *m, c
     return e;
 }
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Row N4: sphere-light direct illumination of the primary surface -- a functional stand-in for the RTXDI passes whose
+ * result Raytracing.hlsl:150-163 reads (DI = directDiffuse + directSpecular, isDIValid = any(DI > 0)), :302 (the first-bounce
+ * hit of a pixel with valid DI contributes no emission) and :381 (radiance += DI).  One emitter chosen uniformly
+ * (LightPreparation.ixx:52-70 enumerates them), one direction uniform in the cone it subtends, own RNG stream.
+ * ---------------------------------------------------------------------------------------------------------------- */
+#define DI_RNG_SALT 0x44495F31u
+
+typedef struct { const uint32_t *ids; uint32_t n; } light_list;
+
+int oracle_sample_sphere_cone(const float P[3], const float C[3], float r, float u1, float u2, float L[3], float *inv_pdf)
+{
+    v3 w = v_sub(V3(C[0], C[1], C[2]), V3(P[0], P[1], P[2]));
+    float d2 = v_dot(w, w), r2 = r * r;
+    L[0] = 0; L[1] = 0; L[2] = 1; *inv_pdf = 0.0f;
+    if (!(d2 > r2)) return 0;
+    v3 wn = v_scale(w, 1.0f / sqrtf(d2));
+    float sin2 = r2 / d2;
+    float cos_max = f_sqrt01(1.0f - sin2);
+    float omc = sin2 / (1.0f + cos_max);
+    float k = u1 * omc;
+    float cos_t = 1.0f - k;
+    float sin_t = f_sqrt01(k * (1.0f + cos_t));
+    float sp, cp;
+    oracle_sincos_2pi(u2, &sp, &cp);
+    basis3 b = get_basis(wn);
+    v3 l = rotate_vector_inverse(b, V3(sin_t * cp, sin_t * sp, cos_t));
+    L[0] = l.x; L[1] = l.y; L[2] = l.z;
+    *inv_pdf = 6.28318530717958647692f * omc;
+    return 1;
+}
+
 /* Raytracing.hlsl:103-415 (DEFAULT permutation) + GBufferGeneration.hlsl:117-232 primary hit.
  * Writes rgba; returns rays cast. */
 static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_t n,
                              const PtSceneData *sd, const PtCamera *cam, const PtGraphicsSettings *gs,
-                             uint32_t px, uint32_t py, float rgba[4], uint64_t *paths_out, trace_t *tr, const tex_ctx *tc)
+                             uint32_t px, uint32_t py, float rgba[4], uint64_t *paths_out, trace_t *tr, const tex_ctx *tc,
+                             const light_list *lights)
 {
     (void)paths_out;
     uint64_t rays = 0;
@@ -837,6 +870,8 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
     hit_t primary;
     cast_ray(sph, n, o, d, tmin, tmax, &primary);
     rays++;
+    const int di_on = gs->IsDIEnabled && lights && lights->n > 0;
+    if (di_on) rays++; /* the DI pass traces the primary ray again */
     if (!primary.hit) { /* miss: Radiance = env (GBufferGeneration.hlsl:223-227); bounce loop returns without writing (:249-252) */
         v3 c = environment_color(sd, d);
         rgba[0] = c.x; rgba[1] = c.y; rgba[2] = c.z; rgba[3] = 1.0f;
@@ -851,6 +886,41 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
     bsdf_init(&primary_bsdf, pe.base, pe.metallic, pe.roughness, pe.ior,
               pe.metallic < 1.0f ? pe.transmission : 0.0f, primary.front); /* :143-150 */
 
+    /* direct illumination of the primary surface (row N4) */
+    v3 DI = V3(0, 0, 0);
+    int di_valid = 0;
+    if (di_on) {
+        uint32_t lrng = oracle_rng_init(px, py, gs->FrameIndex ^ DI_RNG_SALT);
+        float u0 = oracle_rng_float(&lrng), u1 = oracle_rng_float(&lrng), u2 = oracle_rng_float(&lrng);
+        uint32_t j = (uint32_t)(u0 * (float)lights->n);
+        if (j >= lights->n) j = lights->n - 1u;
+        const uint32_t light = lights->ids[j];
+        const PtSphere *ls = &sph[light];
+        float Pp[3] = { primary.P.x, primary.P.y, primary.P.z }, Cc[3] = { ls->cx, ls->cy, ls->cz }, Ll[3], inv_pdf;
+        int ok = oracle_sample_sphere_cone(Pp, Cc, ls->r, u1, u2, Ll, &inv_pdf);
+        v3 L = V3(Ll[0], Ll[1], Ll[2]);
+        surf_t sv;
+        surf_init(&sv, primary.front, primary.N, primary.shadingN);
+        if (light != primary.id && ok && v_dot(sv.FrontNg, L) > 0.0f) {
+            hit_t sh;
+            cast_ray(sph, n, spawn_origin(primary.P, primary.N, primary.offset, L), L, 0.0f, INFINITY, &sh);
+            rays++;
+            if (sh.hit && sh.id == light) {
+                v3 V = v_neg(d);
+                float w[3];
+                lobe_weights(&primary_bsdf, &sv, V, w);
+                v3 f = v_add(bsdf_eval(&primary_bsdf, &sv, L, V, w, 0), bsdf_eval(&primary_bsdf, &sv, L, V, w, 1));
+                const PtMaterial *lm = &mat[light];
+                v3 le = v_scale(V3(lm->EmissiveColor[0], lm->EmissiveColor[1], lm->EmissiveColor[2]), lm->EmissiveStrength);
+                DI = v_scale(v_mul(le, f), inv_pdf * (float)lights->n);
+            }
+        }
+        /* NaN / inf / negative estimates count as no light.  The reference gates :302 on any(DI > 0); with this one-sample
+         * estimator DI = 0 is an ordinary sample value, so the gate is "the pixel has a primary surface" (keeps it unbiased) */
+        if (!(DI.x > 0.0f || DI.y > 0.0f || DI.z > 0.0f) || !f_finite(DI.x) || !f_finite(DI.y) || !f_finite(DI.z)) DI = V3(0, 0, 0);
+        di_valid = 1;
+    }
+
     v3 radiance = V3(0, 0, 0);
     const uint32_t spp = gs->SamplesPerPixel;
     for (uint32_t s = 0; s < spp; s++) { /* :191 */
@@ -862,6 +932,7 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
         int lobe = -1;
         v3 L = V3(0, 0, 0), T = V3(1, 1, 1);
         v3 sample_radiance = V3(0, 0, 0);
+        int via_t = 0;
         for (uint32_t bnc = 0; bnc <= gs->Bounces; bnc++) { /* :213 */
             if (bnc) { /* :219-234 */
                 ro = spawn_origin(hit.P, hit.N, hit.offset, L);
@@ -880,6 +951,9 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
                 const material_eval e = evaluate_material(tc, &mat[hit.id], &hit); /* :293-301 */
                 hit.shadingN = e.shadingN;
                 emission = v_scale(e.emissive_color, e.emissive_strength);
+                /* :302 -- DI covers what the primary surface's reflective lobes receive; a sample that left it through the
+                 * transmission lobe keeps the emission it finds */
+                if (di_valid && bnc == 1 && !via_t) emission = V3(0, 0, 0);
                 bsdf_init(&bsdf, e.base, e.metallic, e.roughness, e.ior, e.transmission, hit.front);
             }
             sample_radiance = v_add(sample_radiance, v_mul(T, emission)); /* :320 */
@@ -898,6 +972,7 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
             v3 f = bsdf_eval(&bsdf, &sv, L, V, w, lobe); /* :341 */
             if (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) { trace_event(tr, s, bnc, &hit, 1, L, T, rng, lobe, 5); break; }
             { float inv_pdf = 1.0f / pdf; T = v_mul(T, v_scale(f, inv_pdf)); } /* :346 */
+            if (bnc == 0) via_t = lobe == 2;
             if (gs->IsRussianRouletteEnabled && bnc > 3) { /* :348-356 */
                 float p = f_max(T.x, f_max(T.y, T.z));
                 if (oracle_rng_float(&rng) >= p) { trace_event(tr, s, bnc, &hit, 1, L, T, rng, lobe, 6); break; }
@@ -913,6 +988,7 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
     } else {
         radiance = V3(0, 0, 0);
     }
+    if (di_on) radiance = v_add(radiance, DI); /* :381 */
     rgba[0] = radiance.x; rgba[1] = radiance.y; rgba[2] = radiance.z; rgba[3] = 1.0f;
     return rays;
 }
@@ -922,6 +998,7 @@ typedef struct {
     const PtSceneData *sd; const PtCamera *cam; const PtGraphicsSettings *gs;
     PtRect rect; uint32_t row_step; float *out;
     const void *tex; /* tex_ctx */
+    const void *lights; /* light_list */
     int tid, nthreads;
     uint64_t rays, paths;
 } job_t;
@@ -1002,7 +1079,7 @@ static void *worker(void *arg)
         if ((int)(k % (uint32_t)j->nthreads) != j->tid) continue;
         for (uint32_t rx = 0; rx < j->rect.w; rx++) {
             float *px = j->out + 4 * ((size_t)ry * j->rect.w + rx);
-            j->rays += render_pixel(j->sph, j->mat, j->n, j->sd, j->cam, j->gs, j->rect.x + rx, j->rect.y + ry, px, &j->paths, NULL, (const tex_ctx *)j->tex);
+            j->rays += render_pixel(j->sph, j->mat, j->n, j->sd, j->cam, j->gs, j->rect.x + rx, j->rect.y + ry, px, &j->paths, NULL, (const tex_ctx *)j->tex, (const light_list *)j->lights);
             j->paths += j->gs->SamplesPerPixel; /* nominal (pixel, sample) pairs */
         }
     }
@@ -1014,7 +1091,7 @@ static int validate(const PtSceneData *sd, const PtGraphicsSettings *gs, uint32_
     if (n == 0) return 1;
     if (gs->RenderSize[0] == 0 || gs->RenderSize[1] == 0 || gs->SamplesPerPixel == 0) return 2;
     if (gs->RenderSize[0] > 65535u || gs->RenderSize[1] > 65535u) return 2; /* (px<<16)|py seed */
-    if (gs->IsDIEnabled || gs->Denoiser) return 3;
+    if (gs->Denoiser) return 3;
     if (sd->EnvironmentLightTextureDescriptor != 0xFFFFFFFFu) return 4;
     return 0;
 }
@@ -1052,6 +1129,14 @@ int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials,
     tex_ctx tc;
     const int textured = textures && textures->n_textures > 0;
     if (textured) tex_ctx_init(&tc, textures);
+    /* emitters in id order (any emission component > 0) */
+    uint32_t *light_ids = (uint32_t *)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
+    light_list ll = { light_ids, 0 };
+    for (uint32_t i = 0; i < n; i++) {
+        const PtMaterial *m = &materials[i];
+        if (m->EmissiveStrength * m->EmissiveColor[0] > 0.0f || m->EmissiveStrength * m->EmissiveColor[1] > 0.0f || m->EmissiveStrength * m->EmissiveColor[2] > 0.0f)
+            light_ids[ll.n++] = i;
+    }
     if (rect->x + rect->w > gs->RenderSize[0] || rect->y + rect->h > gs->RenderSize[1]) return 5;
     if (row_step == 0) row_step = 1;
     if (threads < 1) threads = 1;
@@ -1063,6 +1148,7 @@ int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials,
         j->sph = spheres; j->mat = materials; j->n = n; j->sd = scene; j->cam = camera; j->gs = gs;
         j->rect = *rect; j->row_step = row_step; j->out = out_rgba; j->tid = t; j->nthreads = threads;
         j->tex = textured ? &tc : NULL;
+        j->lights = &ll;
     }
     if (threads == 1) worker(&jobs[0]);
     else {
@@ -1073,7 +1159,7 @@ int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials,
         stats->rays = 0; stats->paths = 0;
         for (int t = 0; t < threads; t++) { stats->rays += jobs[t].rays; stats->paths += jobs[t].paths; }
     }
-    free(jobs); free(th);
+    free(jobs); free(th); free(light_ids);
     return 0;
 }
 
@@ -1086,7 +1172,7 @@ int oracle_trace_pixel(const PtSphere *spheres, const PtMaterial *materials, uin
     if (err) return err;
     trace_t tr = { events, max_events, 0 };
     float rgba[4]; uint64_t paths = 0;
-    render_pixel(spheres, materials, n, scene, camera, gs, px, py, rgba, &paths, &tr, NULL);
+    render_pixel(spheres, materials, n, scene, camera, gs, px, py, rgba, &paths, &tr, NULL, NULL);
     *n_events = tr.n_events;
     return 0;
 }

@@ -47,6 +47,8 @@ int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials,
                            const PtSceneData *scene, const PtCamera *camera,
                            const PtGraphicsSettings *gs, const PtRect *rect, uint32_t row_step,
                            float *out_rgba, OracleStats *stats, int threads, const OracleTextures *textures);
+/* leaf of row N4: uniform direction in the cone the sphere (C, r) subtends from P; returns 0 when P is inside the sphere */
+int oracle_sample_sphere_cone(const float P[3], const float C[3], float r, float u1, float u2, float L[3], float *inv_pdf);
 /* leaves of row N1 */
 float oracle_atan2(float y, float x);
 void oracle_sphere_uv(const float n[3], float uv[2]);

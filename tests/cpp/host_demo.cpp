@@ -49,7 +49,7 @@ int main(int argc, char** argv)
         std::fclose(f);
 
         // error behaviour mirrors the reference's exceptions: an unsupported setting throws from Render
-        gs.IsDIEnabled = true;
+        gs.Denoiser = dxrs::Denoiser::NRDReBLUR;
         raytracing.SetConstants(gs);  // noexcept, like the reference
         bool threw = false;
         try { raytracing.Render(radiance); } catch (const std::exception& e) { threw = true; std::printf("expected error: %s\n", e.what()); }

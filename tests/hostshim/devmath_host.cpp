@@ -4,6 +4,7 @@
 #include "../../directx-raytracing-spheres-demo_amd/csrc/pt_bsdf.h"
 #include "../../directx-raytracing-spheres-demo_amd/csrc/pt_post.h"
 #include "../../directx-raytracing-spheres-demo_amd/csrc/pt_texture.h"
+#include "../../directx-raytracing-spheres-demo_amd/csrc/pt_light.h"
 #include <vector>
 
 using namespace pt;
@@ -70,6 +71,14 @@ void dev_accumulate(float* accum, const float* rad, uint32_t n_pixels, uint32_t 
 {
     const float inv = 1.0f / (float)(frames_accumulated + 1u);
     for (uint32_t i = 0; i < 4u * n_pixels; i++) accum[i] = accumulate_value(accum[i], rad[i], inv, frames_accumulated == 0);
+}
+
+// ---- row N4 leaf
+int dev_sample_sphere_cone(const float P[3], const float C[3], float r, float u1, float u2, float L[3], float* inv_pdf)
+{
+    const LightSample s = sample_sphere_cone(make_f3(P[0], P[1], P[2]), make_f3(C[0], C[1], C[2]), r, u1, u2);
+    L[0] = s.L.x; L[1] = s.L.y; L[2] = s.L.z; *inv_pdf = s.inv_pdf;
+    return s.valid ? 1 : 0;
 }
 
 // ---- row N1 leaves

@@ -24,7 +24,7 @@ def test_cpp_host_matches_python_path(dxrs, host, renderer, demo_exe, tmp_path, 
     out = str(tmp_path / "frame.f32")
     res = subprocess.run([demo_exe, scene, str(w), str(h), str(bounces), str(spp), str(frame), out], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
-    assert "expected error" in res.stdout and "IsDIEnabled" in res.stdout
+    assert "expected error" in res.stdout and "Denoiser" in res.stdout
     img_cpp = np.fromfile(out, dtype=np.float32).reshape(h, w, 4)
     kind = dxrs.host.SCENE_SMALL if scene == "small" else dxrs.host.SCENE_DEMO
     spheres, materials, sd = host.scene(kind, seed=0)
