@@ -44,6 +44,7 @@ def main():
                     help="demo scene in motion (closed-form springs + Moon orbit, 1/60 s per frame): per-frame sphere upload + LBVH refit inside the timed region")
     ap.add_argument("--textures", action="store_true",
                     help="demo scene with its textured objects (row N1: Alien-Metal, Moon, Earth; procedural stand-ins for the reference's image files)")
+    ap.add_argument("--di", action="store_true", help="IsDIEnabled = 1 (row N4): sphere-light direct illumination pass before the bounce passes")
     ap.add_argument("--force-tiles", action="store_true", help="run the tile / gather / un-swizzle path even with one rank (rehearsal of the N > 1 path)")
     ap.add_argument("--root-weight", type=int, default=-1,
                     help="tiled path: shares of the frame rank 0 renders (every other rank renders one; 0 = rank 0 renders everything); "
@@ -98,7 +99,7 @@ def main():
             raise SystemExit("--textures is defined for the demo scene")
         tex = host.demo_textures(0, 0.0)
         r.set_textures(tex)
-    gs = graphics_settings(w, h, frame_index=0, bounces=args.bounces, spp=args.spp)
+    gs = graphics_settings(w, h, frame_index=0, bounces=args.bounces, spp=args.spp, di=args.di)
     r.set_constants(gs)
     cams = [host.camera(w, h, jitter_index=k, jitter_count=8) for k in range(8)]
 
@@ -213,6 +214,7 @@ def main():
             "config": {
                 "workload": f"{args.scene} sphere scene (seed {1 if args.scene == 'procedural' else 0}, {len(spheres)} spheres), {w}x{h}, {args.spp} spp, {args.bounces} bounces, RR on, sky env"
                             + (", textured (Alien-Metal, Moon, Earth; procedural stand-in images)" if args.textures else "")
+                            + (", sphere-light direct illumination (IsDIEnabled)" if args.di else "")
                             + (f", 32x32 tiles interleaved over {world} GPU(s) + RCCL gather to rank 0" if tiled else ""),
                 **({"tile_exchange": {"root_weight": ex.root_weight, "frames_per_gather": ex.batch, "root_tiles": ex.n_root,
                                       "tiles_per_other_rank": ex.n_other, "autotune": tune_log or None}} if tiled else {}),
@@ -262,7 +264,7 @@ def main():
         traffic = None
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the guide prescribes)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pmc.get("workload") == f"{args.scene}-{w}x{h}-{args.spp}spp-{args.bounces}b" and not split:
+            if pmc.get("workload") == f"{args.scene}-{w}x{h}-{args.spp}spp-{args.bounces}b" and not split and not args.di and not args.textures:
                 key = "bounce<loop>" if "loop" in name else "bounce<wavefront>"
                 traffic = pmc[key]["hbm_bytes_per_launch"]
         except Exception:
@@ -295,7 +297,7 @@ def main():
         # on 256 CUs x 4 SIMDs at the measured 2.35 GHz (tools/experiments/clock.hip)
         valu = None
         try:
-            if pmc.get("workload") == f"{args.scene}-{w}x{h}-{args.spp}spp-{args.bounces}b" and not split and not args.textures and not tiled:
+            if pmc.get("workload") == f"{args.scene}-{w}x{h}-{args.spp}spp-{args.bounces}b" and not split and not args.textures and not tiled and not args.di:
                 sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))["kernels"]
                 per_frame = sum(k["valu_insts_per_launch"] for k in sq.values())
                 bound_ms = per_frame * 4 / 1024 / 2.35e9 * 1e3
