@@ -151,3 +151,45 @@ def test_frames_in_flight(dxrs, host, renderer, lanes):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     finally:
         r2.close()
+
+
+def test_everything_together_tiles_textures_di_in_flight(dxrs, host, oracle):
+    """the optional pieces composed: a weighted tile partition rendered with three frames in flight, textured spheres with
+    per-frame rotations, sphere-light direct illumination, spp 2 -- every assembled frame equals the oracle's full frame"""
+    import torch
+    from dxrs_amd import tiles
+    t = dxrs.types
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    w, h, world, weight, n_frames = 320, 200, 3, 2, 5
+    tstream = torch.cuda.Stream(); torch.cuda.set_stream(tstream)
+    root = tiles.weighted_partition(0, world, weight)
+    n_root = tiles.range_tiles_count(w, h, *root)
+    n_other = tiles.range_tiles_count(w, h, *tiles.weighted_partition(1, world, weight))
+    ts2 = 32 * 32
+    rs = [dxrs.Renderer(stream=tstream.cuda_stream, frames_in_flight=3) for _ in range(world)]  # one context per emulated rank
+    for rank, r in enumerate(rs):
+        r.set_scene(spheres, materials, sd)
+        r.set_textures(host.demo_textures(0, 0.0))
+        r.set_partition_ex(*tiles.weighted_partition(rank, world, weight))
+    own = [torch.zeros((n_root * ts2, 4), dtype=torch.float32, device="cuda") for _ in range(n_frames)]
+    others = [torch.zeros((world - 1, n_other * ts2, 4), dtype=torch.float32, device="cuda") for _ in range(n_frames)]
+    frames = [torch.full((h, w, 4), -1.0, dtype=torch.float32, device="cuda") for _ in range(n_frames)]
+    tex = [host.demo_textures(0, 0.5 * k) for k in range(n_frames)]
+    gss = [t.graphics_settings(w, h, frame_index=k, bounces=4, spp=2, di=True) for k in range(n_frames)]
+    cams = [host.camera(w, h, jitter_index=k) for k in range(n_frames)]
+    for k in range(n_frames):
+        for rank, r in enumerate(rs):
+            r.update_rotations(tex[k].rotations)
+            r.set_camera(cams[k]); r.set_constants(gss[k])
+            r.render_tiles((own[k] if rank == 0 else others[k][rank - 1]).data_ptr())
+        rs[0].unpack_tiles_ex(own[k].data_ptr(), 0, 1, root[0], root[1], root[2], frames[k].data_ptr())
+        rs[0].unpack_tiles_ex(others[k].data_ptr(), others[k].shape[1], world - 1, root[1], 1, root[2], frames[k].data_ptr())
+    for r in rs:
+        r.synchronize()
+    torch.cuda.synchronize()
+    for k in range(n_frames):
+        ref, _ = oracle.render(spheres, materials, sd, cams[k], gss[k], threads=8, textures=tex[k])
+        got = frames[k].cpu().numpy()
+        assert np.array_equal(got.view(np.uint32)[..., :3], ref.view(np.uint32)[..., :3]), f"frame {k}"
+    for r in rs:
+        r.close()
