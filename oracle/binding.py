@@ -87,6 +87,10 @@ class Oracle:
         lib.oracle_render_textured.argtypes = [vp, vp, u32, vp, vp, vp, C.POINTER(_Rect), u32, vp, C.POINTER(OracleStats), C.c_int, vp]
         lib.oracle_sample_texture.restype = None
         lib.oracle_sample_texture.argtypes = [vp, u32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.oracle_closest_hit.restype = C.c_int
+        lib.oracle_closest_hit.argtypes = [vp, u32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int, C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(u32)]
+        lib.oracle_free_bvh.restype = None
+        lib.oracle_free_bvh.argtypes = [vp]
         lib.oracle_tonemap.restype = None
         lib.oracle_tonemap.argtypes = [vp, u32, vp, vp]
         declare_leaf_api(lib, "oracle_")
@@ -123,6 +127,22 @@ class Oracle:
         if rc:
             raise RuntimeError(f"oracle_render failed ({rc})")
         return out, stats
+
+    def closest_hits(self, spheres, origins, directions, tmin=0.0, tmax=float("inf"), use_bvh=True):
+        """closest hit of every ray: (t float32[n], id uint32[n]) through the brute-force loop or the oracle's own BVH"""
+        spheres = np.ascontiguousarray(spheres)
+        o = np.ascontiguousarray(origins, dtype=np.float32); d = np.ascontiguousarray(directions, dtype=np.float32)
+        t = np.zeros(len(o), dtype=np.float32); ids = np.zeros(len(o), dtype=np.uint32)
+        cache = C.c_void_p(None)
+        pf = C.POINTER(C.c_float)
+        for i in range(len(o)):
+            tt, ii = C.c_float(), C.c_uint32()
+            self.lib.oracle_closest_hit(spheres.ctypes.data, len(spheres), o[i].ctypes.data_as(pf), d[i].ctypes.data_as(pf), tmin, tmax, 1 if use_bvh else 0,
+                                        C.byref(cache) if use_bvh else None, C.byref(tt), C.byref(ii))
+            t[i], ids[i] = tt.value, ii.value
+        if cache.value:
+            self.lib.oracle_free_bvh(cache)
+        return t, ids
 
     def tonemap(self, hdr, params):
         """hdr (..., 4) float32 -> packed uint32 (...): the display transform of row N3"""

@@ -361,15 +361,166 @@ typedef struct {
     v3 shadingN;  /* N or -N (HitInfo.hlsli:60-64) */
 } hit_t;
 
-/* closest hit, brute force; ties -> lowest id (strict < in id order) */
-static void cast_ray(const PtSphere *sph, uint32_t n, v3 o, v3 d, float tmin, float tmax, hit_t *h)
+/* ------------------------------------------------------------------------------------------------------------------
+ * Closest hit.  Brute force over all spheres is the definition (ties -> lowest id: strict < in id order).  For scenes of
+ * more than OBVH_MIN_SPHERES spheres the oracle builds its own acceleration structure -- a median-split BVH with padded
+ * boxes and a double-precision slab test, unrelated to the product's LBVH -- that returns exactly the brute-force answer
+ * (tests/test_oracle_kat.py compares the two); it makes the 2^20-sphere configuration runnable on the CPU (BASELINE.md
+ * section 2: "CPU-BVH (C5)").
+ * ---------------------------------------------------------------------------------------------------------------- */
+#define OBVH_MIN_SPHERES 64u
+#define OBVH_LEAF 4u
+
+typedef struct {
+    float lo[3], hi[3];
+    uint32_t left, right; /* children (internal) */
+    uint32_t first, count; /* leaf: prim[first .. first + count) ; count == 0 for internal nodes */
+} onode;
+
+typedef struct {
+    onode *nodes;
+    uint32_t *prim;
+    uint32_t n_nodes;
+} obvh;
+
+static void obvh_bounds(const PtSphere *sph, const uint32_t *prim, uint32_t first, uint32_t count, float pad, float lo[3], float hi[3])
+{
+    for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+    for (uint32_t k = first; k < first + count; k++) {
+        const PtSphere *s = &sph[prim[k]];
+        const float c[3] = { s->cx, s->cy, s->cz };
+        for (int a = 0; a < 3; a++) {
+            lo[a] = f_min(lo[a], c[a] - s->r - pad);
+            hi[a] = f_max(hi[a], c[a] + s->r + pad);
+        }
+    }
+}
+
+static float obvh_key(const PtSphere *s, int axis) { return axis == 0 ? s->cx : (axis == 1 ? s->cy : s->cz); }
+
+/* quickselect: afterwards prim[first .. mid) have centroid[axis] <= those of prim[mid .. last) */
+static void obvh_select(const PtSphere *sph, uint32_t *prim, uint32_t first, uint32_t last, uint32_t mid, int axis)
+{
+    uint32_t lo = first, hi = last; /* [lo, hi) */
+    uint32_t seed = 12345u;
+    while (hi - lo > 1) {
+        seed = seed * 1664525u + 1013904223u;
+        const float pivot = obvh_key(&sph[prim[lo + seed % (hi - lo)]], axis);
+        uint32_t i = lo, j = lo, k = hi; /* three-way partition: [lo,i) < pivot, [i,j) == pivot, [k,hi) > pivot */
+        while (j < k) {
+            const float v = obvh_key(&sph[prim[j]], axis);
+            if (v < pivot) { uint32_t t = prim[i]; prim[i] = prim[j]; prim[j] = t; i++; j++; }
+            else if (v > pivot) { k--; uint32_t t = prim[j]; prim[j] = prim[k]; prim[k] = t; }
+            else j++;
+        }
+        if (mid < i) hi = i;
+        else if (mid >= k) lo = k;
+        else return; /* mid falls in the run of equal keys */
+    }
+}
+
+static obvh *obvh_build(const PtSphere *sph, uint32_t n)
+{
+    obvh *b = (obvh *)calloc(1, sizeof(obvh));
+    b->prim = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+    b->nodes = (onode *)malloc((size_t)(2u * n) * sizeof(onode));
+    for (uint32_t i = 0; i < n; i++) b->prim[i] = i;
+    /* padding: 2^-15 of the largest coordinate magnitude (4x the product's, so the structure is conservative in its own right) */
+    float smax = 0.0f;
+    for (uint32_t i = 0; i < n; i++) {
+        const PtSphere *s = &sph[i];
+        smax = f_max(smax, f_max(f_max(f_abs(s->cx) + s->r, f_abs(s->cy) + s->r), f_abs(s->cz) + s->r));
+    }
+    const float pad = smax * 3.0517578125e-05f;
+    uint32_t *stack = (uint32_t *)malloc((size_t)(2u * n + 2u) * sizeof(uint32_t));
+    uint32_t sp = 0;
+    b->n_nodes = 1;
+    b->nodes[0].first = 0; b->nodes[0].count = n;
+    stack[sp++] = 0;
+    while (sp) {
+        onode *nd = &b->nodes[stack[--sp]];
+        obvh_bounds(sph, b->prim, nd->first, nd->count, pad, nd->lo, nd->hi);
+        if (nd->count <= OBVH_LEAF) continue;
+        /* split at the median of the centroids along their widest axis */
+        float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (uint32_t k = nd->first; k < nd->first + nd->count; k++)
+            for (int a = 0; a < 3; a++) {
+                const float v = obvh_key(&sph[b->prim[k]], a);
+                clo[a] = f_min(clo[a], v); chi[a] = f_max(chi[a], v);
+            }
+        int axis = 0;
+        if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+        if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+        const uint32_t mid = nd->first + nd->count / 2u;
+        obvh_select(sph, b->prim, nd->first, nd->first + nd->count, mid, axis);
+        const uint32_t l = b->n_nodes++, r = b->n_nodes++;
+        b->nodes[l].first = nd->first; b->nodes[l].count = mid - nd->first;
+        b->nodes[r].first = mid; b->nodes[r].count = nd->first + nd->count - mid;
+        nd->left = l; nd->right = r; nd->count = 0;
+        stack[sp++] = l; stack[sp++] = r;
+    }
+    free(stack);
+    return b;
+}
+
+static void obvh_free(obvh *b)
+{
+    if (!b) return;
+    free(b->nodes); free(b->prim); free(b);
+}
+
+/* conservative ray / box overlap on [tmin, tmax] in double precision (the boxes are padded far beyond its rounding) */
+static int obvh_hits_box(const onode *nd, const double o[3], const double inv[3], double tmin, double tmax)
+{
+    double t0 = tmin, t1 = tmax;
+    for (int a = 0; a < 3; a++) {
+        double ta = ((double)nd->lo[a] - o[a]) * inv[a], tb = ((double)nd->hi[a] - o[a]) * inv[a];
+        if (ta != ta || tb != tb) continue; /* 0 * inf: the origin lies on a plane of a slab the ray is parallel to */
+        if (ta > tb) { double t = ta; ta = tb; tb = t; }
+        if (ta > t0) t0 = ta;
+        if (tb < t1) t1 = tb;
+    }
+    return t0 <= t1 * (1.0 + 1e-12) + 1e-300;
+}
+
+static void closest_hit_id(const obvh *b, const PtSphere *sph, uint32_t n, v3 o, v3 d, float tmin, float tmax, float *best_t, uint32_t *best_id)
 {
     float best = tmax;
-    uint32_t best_id = 0xFFFFFFFFu;
-    for (uint32_t i = 0; i < n; i++) {
-        float t;
-        if (intersect_sphere(o, d, tmin, best, &sph[i], &t)) { best = t; best_id = i; }
+    uint32_t id = 0xFFFFFFFFu;
+    if (!b) {
+        for (uint32_t i = 0; i < n; i++) {
+            float t;
+            if (intersect_sphere(o, d, tmin, best, &sph[i], &t)) { best = t; id = i; }
+        }
+    } else {
+        const double oo[3] = { o.x, o.y, o.z };
+        const double inv[3] = { 1.0 / (double)d.x, 1.0 / (double)d.y, 1.0 / (double)d.z };
+        uint32_t stack[128];
+        uint32_t sp = 0;
+        stack[sp++] = 0;
+        while (sp) {
+            const onode *nd = &b->nodes[stack[--sp]];
+            if (!obvh_hits_box(nd, oo, inv, (double)tmin, (double)best)) continue;
+            if (nd->count) {
+                for (uint32_t k = nd->first; k < nd->first + nd->count; k++) {
+                    const uint32_t i = b->prim[k];
+                    float t;
+                    /* same acceptance as the brute-force loop: inside (tmin, tmax); nearer wins, ties go to the lower id */
+                    if (intersect_sphere(o, d, tmin, tmax, &sph[i], &t) && (t < best || (t == best && id != 0xFFFFFFFFu && i < id))) { best = t; id = i; }
+                }
+            } else if (sp + 2 <= 128) {
+                stack[sp++] = nd->left; stack[sp++] = nd->right;
+            }
+        }
     }
+    *best_t = best; *best_id = id;
+}
+
+static void cast_ray(const void *accel, const PtSphere *sph, uint32_t n, v3 o, v3 d, float tmin, float tmax, hit_t *h)
+{
+    float best;
+    uint32_t best_id;
+    closest_hit_id((const obvh *)accel, sph, n, o, d, tmin, tmax, &best, &best_id);
     h->hit = best_id != 0xFFFFFFFFu;
     h->id = best_id;
     h->t = best;
@@ -386,6 +537,22 @@ static void cast_ray(const PtSphere *sph, uint32_t n, v3 o, v3 d, float tmin, fl
         h->shadingN = h->front ? N : v_neg(N);
     }
 }
+
+/* test hook: closest hit of one ray through the brute-force loop (use_bvh = 0) or the oracle's BVH */
+int oracle_closest_hit(const PtSphere *spheres, uint32_t n, const float o[3], const float d[3], float tmin, float tmax, int use_bvh,
+                       void **bvh_cache, float *t, uint32_t *id)
+{
+    obvh *b = NULL;
+    if (use_bvh) {
+        if (bvh_cache && *bvh_cache) b = (obvh *)*bvh_cache;
+        else { b = obvh_build(spheres, n); if (bvh_cache) *bvh_cache = b; }
+    }
+    closest_hit_id(b, spheres, n, V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), tmin, tmax, t, id);
+    if (use_bvh && !bvh_cache) obvh_free(b);
+    return *id != 0xFFFFFFFFu;
+}
+void oracle_free_bvh(void *bvh) { obvh_free((obvh *)bvh); }
+
 void oracle_hit_frame(const float o[3], const float d[3], float t, const PtSphere *s,
                       float P[3], float N[3], float *offset, int *front)
 {
@@ -858,7 +1025,7 @@ int oracle_sample_sphere_cone(const float P[3], const float C[3], float r, float
 static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_t n,
                              const PtSceneData *sd, const PtCamera *cam, const PtGraphicsSettings *gs,
                              uint32_t px, uint32_t py, float rgba[4], uint64_t *paths_out, trace_t *tr, const tex_ctx *tc,
-                             const light_list *lights)
+                             const light_list *lights, const void *accel)
 {
     (void)paths_out;
     uint64_t rays = 0;
@@ -868,7 +1035,7 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
 
     /* primary-hit pass (GBufferGeneration.hlsl:128-230) */
     hit_t primary;
-    cast_ray(sph, n, o, d, tmin, tmax, &primary);
+    cast_ray(accel, sph, n, o, d, tmin, tmax, &primary);
     rays++;
     const int di_on = gs->IsDIEnabled && lights && lights->n > 0;
     if (di_on) rays++; /* the DI pass traces the primary ray again */
@@ -903,7 +1070,7 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
         surf_init(&sv, primary.front, primary.N, primary.shadingN);
         if (light != primary.id && ok && v_dot(sv.FrontNg, L) > 0.0f) {
             hit_t sh;
-            cast_ray(sph, n, spawn_origin(primary.P, primary.N, primary.offset, L), L, 0.0f, INFINITY, &sh);
+            cast_ray(accel, sph, n, spawn_origin(primary.P, primary.N, primary.offset, L), L, 0.0f, INFINITY, &sh);
             rays++;
             if (sh.hit && sh.id == light) {
                 v3 V = v_neg(d);
@@ -937,7 +1104,7 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
             if (bnc) { /* :219-234 */
                 ro = spawn_origin(hit.P, hit.N, hit.offset, L);
                 rd = L;
-                cast_ray(sph, n, ro, rd, 0.0f, INFINITY, &hit);
+                cast_ray(accel, sph, n, ro, rd, 0.0f, INFINITY, &hit);
                 is_hit = hit.hit;
                 rays++;
             }
@@ -999,6 +1166,7 @@ typedef struct {
     PtRect rect; uint32_t row_step; float *out;
     const void *tex; /* tex_ctx */
     const void *lights; /* light_list */
+    const void *accel;  /* obvh or NULL (brute force) */
     int tid, nthreads;
     uint64_t rays, paths;
 } job_t;
@@ -1079,7 +1247,7 @@ static void *worker(void *arg)
         if ((int)(k % (uint32_t)j->nthreads) != j->tid) continue;
         for (uint32_t rx = 0; rx < j->rect.w; rx++) {
             float *px = j->out + 4 * ((size_t)ry * j->rect.w + rx);
-            j->rays += render_pixel(j->sph, j->mat, j->n, j->sd, j->cam, j->gs, j->rect.x + rx, j->rect.y + ry, px, &j->paths, NULL, (const tex_ctx *)j->tex, (const light_list *)j->lights);
+            j->rays += render_pixel(j->sph, j->mat, j->n, j->sd, j->cam, j->gs, j->rect.x + rx, j->rect.y + ry, px, &j->paths, NULL, (const tex_ctx *)j->tex, (const light_list *)j->lights, j->accel);
             j->paths += j->gs->SamplesPerPixel; /* nominal (pixel, sample) pairs */
         }
     }
@@ -1129,6 +1297,29 @@ int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials,
     tex_ctx tc;
     const int textured = textures && textures->n_textures > 0;
     if (textured) tex_ctx_init(&tc, textures);
+    /* ORACLE_NO_BVH=1 forces the brute-force definition (the tests compare whole frames both ways).  The structure of the
+     * last scene is kept between calls (keyed by a hash of the sphere data), so that timing consecutive frames of one scene
+     * -- bench.py's cpu_baseline -- measures rendering, as the GPU figure does, not rebuilding.  Not re-entrant: one
+     * oracle_render at a time per process, which is how tests/ and bench.py use it. */
+    static obvh *cached = NULL;
+    static uint64_t cached_hash = 0;
+    static uint32_t cached_n = 0;
+    obvh *accel = NULL;
+    if (n > OBVH_MIN_SPHERES && !getenv("ORACLE_NO_BVH")) {
+        uint64_t hsh = 1469598103934665603ull;
+        for (uint32_t i = 0; i < n; i++) { /* PtSphere = 16 bytes = two 64-bit words */
+            uint64_t w64[2];
+            memcpy(w64, &spheres[i], sizeof w64);
+            hsh = (hsh ^ w64[0]) * 1099511628211ull;
+            hsh = (hsh ^ w64[1]) * 1099511628211ull;
+        }
+        if (!cached || cached_n != n || cached_hash != hsh) {
+            obvh_free(cached);
+            cached = obvh_build(spheres, n);
+            cached_n = n; cached_hash = hsh;
+        }
+        accel = cached;
+    }
     /* emitters in id order (any emission component > 0) */
     uint32_t *light_ids = (uint32_t *)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
     light_list ll = { light_ids, 0 };
@@ -1149,6 +1340,7 @@ int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials,
         j->rect = *rect; j->row_step = row_step; j->out = out_rgba; j->tid = t; j->nthreads = threads;
         j->tex = textured ? &tc : NULL;
         j->lights = &ll;
+        j->accel = accel;
     }
     if (threads == 1) worker(&jobs[0]);
     else {
@@ -1172,7 +1364,7 @@ int oracle_trace_pixel(const PtSphere *spheres, const PtMaterial *materials, uin
     if (err) return err;
     trace_t tr = { events, max_events, 0 };
     float rgba[4]; uint64_t paths = 0;
-    render_pixel(spheres, materials, n, scene, camera, gs, px, py, rgba, &paths, &tr, NULL, NULL);
+    render_pixel(spheres, materials, n, scene, camera, gs, px, py, rgba, &paths, &tr, NULL, NULL, NULL);
     *n_events = tr.n_events;
     return 0;
 }

@@ -47,6 +47,11 @@ int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials,
                            const PtSceneData *scene, const PtCamera *camera,
                            const PtGraphicsSettings *gs, const PtRect *rect, uint32_t row_step,
                            float *out_rgba, OracleStats *stats, int threads, const OracleTextures *textures);
+/* Closest hit of one ray: brute force (use_bvh = 0, the definition) or the oracle's own median-split BVH, which must agree
+ * exactly.  bvh_cache (may be NULL): *bvh_cache keeps the built structure between calls; release with oracle_free_bvh. */
+int oracle_closest_hit(const PtSphere *spheres, uint32_t n, const float o[3], const float d[3], float tmin, float tmax, int use_bvh,
+                       void **bvh_cache, float *t, uint32_t *id);
+void oracle_free_bvh(void *bvh);
 /* leaf of row N4: uniform direction in the cone the sphere (C, r) subtends from P; returns 0 when P is inside the sphere */
 int oracle_sample_sphere_cone(const float P[3], const float C[3], float r, float u1, float u2, float L[3], float *inv_pdf);
 /* leaves of row N1 */

@@ -125,3 +125,19 @@ def test_single_sphere_scene(dxrs, host, oracle):
         assert st.rays == ost.rays and np.array_equal(img.view(np.uint32)[..., :3], ref.view(np.uint32)[..., :3])
     finally:
         r.close()
+
+
+def test_million_sphere_frame_matches_oracle(dxrs, host, oracle, renderer):
+    """BASELINE config C5's scene (2^20 procedural spheres + ground) at a small frame size: the whole pipeline (device LBVH
+    build, global-memory traversal with ray replacement, split schedule, looping tail) against the oracle, which answers
+    through its own, unrelated BVH -- bit-identical radiance and ray count"""
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_PROCEDURAL, seed=1, count=1 << 20)
+    w, h = 192, 108
+    cam = host.camera(w, h, jitter_index=3)
+    for (bounces, spp) in ((8, 1), (3, 2)):
+        gs = dxrs.types.graphics_settings(w, h, frame_index=3, bounces=bounces, spp=spp)
+        renderer.set_scene(spheres, materials, sd); renderer.set_camera(cam); renderer.set_constants(gs)
+        img, st = renderer.render()
+        ref, ost = oracle.render(spheres, materials, sd, cam, gs, threads=8)
+        assert st.rays == ost.rays
+        assert np.array_equal(img.view(np.uint32)[..., :3], ref.view(np.uint32)[..., :3])

@@ -226,3 +226,56 @@ def test_rng_golden_vectors(oracle):
         assert st == int(golden[i, 0])
         for k in range(16):
             st = h(st); assert st == int(golden[i, 1 + k])
+
+
+def test_oracle_bvh_equals_brute_force(dxrs, host, oracle):
+    """the oracle's own median-split BVH (used above 64 spheres; it makes the 2^20-sphere configuration runnable on the CPU) returns
+    exactly the brute-force closest hit -- t bit for bit and the lowest id on ties -- on overlapping, nested, coincident and
+    wildly different-sized spheres, for rays from outside, from inside, from sphere surfaces and parallel to the axes"""
+    rng = np.random.default_rng(42)
+    for style in range(4):
+        n = [300, 1000, 80, 5000][style]
+        s = np.zeros(n, dtype=dxrs.SPHERE_DTYPE)
+        if style == 0:
+            s["cx"], s["cy"], s["cz"] = rng.uniform(-6, 6, n), rng.uniform(-4, 4, n), rng.uniform(-8, 8, n)
+            s["r"] = np.exp(rng.uniform(np.log(0.05), np.log(3.0), n))
+        elif style == 1:
+            s["cx"], s["cy"], s["cz"] = rng.uniform(-50, 50, n), rng.uniform(0, 2, n), rng.uniform(-50, 50, n)
+            s["r"] = rng.uniform(0.02, 0.3, n)
+            s[0] = (0, -1000.2, 0, 1000.0)
+        elif style == 2:  # coincident duplicates: ties must go to the lowest id
+            base = 20
+            s["cx"][:base], s["cy"][:base], s["cz"][:base] = rng.uniform(-4, 4, base), rng.uniform(-3, 3, base), rng.uniform(-6, 6, base)
+            s["r"][:base] = rng.uniform(0.3, 2.0, base)
+            for i in range(base, n):
+                s[i] = s[rng.integers(0, base)]
+        else:
+            s["cx"], s["cy"], s["cz"] = rng.normal(0, 3, n), rng.normal(0, 3, n), rng.normal(0, 3, n)
+            s["r"] = np.exp(rng.uniform(np.log(1e-3), np.log(1.0), n))
+        m = 1500
+        c = np.stack([s["cx"], s["cy"], s["cz"]], 1).astype(np.float64)
+        o = rng.uniform(c.min(0) - 2, c.max(0) + 2, (m, 3))
+        pick = rng.integers(0, n, m)
+        d = np.where((np.arange(m) % 2 == 0)[:, None], c[pick] + rng.normal(size=(m, 3)) * s["r"][pick, None] * 0.7 - o, rng.normal(size=(m, 3)))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        k = np.arange(m) % 4 == 1  # origins on sphere surfaces (the secondary-ray case)
+        nrm = rng.normal(size=(m, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        o[k] = c[pick[k]] + nrm[k] * s["r"][pick[k], None] * (1 + 2 ** -14)
+        d32 = d.astype(np.float32)
+        ax = np.arange(m) % 16 == 3
+        d32[ax, rng.integers(0, 3)] = 0.0
+        d32 /= np.linalg.norm(d32.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+        tb, ib = oracle.closest_hits(s, o, d32, use_bvh=False)
+        ta, ia = oracle.closest_hits(s, o, d32, use_bvh=True)
+        assert np.array_equal(ib, ia) and np.array_equal(tb.view(np.uint32), ta.view(np.uint32)), style
+        assert (ib != 0xFFFFFFFF).mean() > 0.2
+
+
+def test_oracle_frame_same_with_and_without_bvh(dxrs, host, oracle, monkeypatch):
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)  # 441 spheres: above the BVH threshold
+    w, h = 96, 54
+    cam, gs = host.camera(w, h), dxrs.types.graphics_settings(w, h, bounces=5, spp=2)
+    a, sa = oracle.render(spheres, materials, sd, cam, gs, threads=8)
+    monkeypatch.setenv("ORACLE_NO_BVH", "1")
+    b, sb = oracle.render(spheres, materials, sd, cam, gs, threads=8)
+    assert sa.rays == sb.rays and np.array_equal(a.view(np.uint32), b.view(np.uint32))
