@@ -16,7 +16,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR
 # every symbol include/pt_api.h declares
 API_SYMBOLS = [
     "pt_create", "pt_destroy", "pt_set_scene", "pt_build_accel", "pt_update_spheres", "pt_refit_accel", "pt_set_camera", "pt_set_constants", "pt_render",
-    "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_set_partition_ex", "pt_tiles_count_ex", "pt_unpack_tiles_ex", "pt_tonemap", "pt_accumulate", "pt_set_textures", "pt_update_rotations", "pt_trace_rays", "pt_trace_rays_stats", "pt_accel_download",
+    "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_set_partition_ex", "pt_tiles_count_ex", "pt_unpack_tiles_ex", "pt_tonemap", "pt_accumulate", "pt_set_textures", "pt_update_rotations", "pt_pack_rgb", "pt_unpack_tiles_rgb", "pt_trace_rays", "pt_trace_rays_stats", "pt_accel_download",
     "pt_accel_download_order", "pt_lbvh_build_host", "pt_set_profiling", "pt_get_profile", "pt_get_totals", "pt_get_queue_sizes", "pt_synchronize", "pt_last_error", "pt_version",
 ]
 
@@ -70,6 +70,10 @@ class HipLib:
         lib.pt_tiles_count_ex.argtypes = [vp, u32, u32, u32]
         lib.pt_unpack_tiles_ex.restype = C.c_int
         lib.pt_unpack_tiles_ex.argtypes = [vp, vp, C.c_uint64, u32, u32, u32, u32, vp]
+        lib.pt_pack_rgb.restype = C.c_int
+        lib.pt_pack_rgb.argtypes = [vp, vp, C.c_uint64, vp]
+        lib.pt_unpack_tiles_rgb.restype = C.c_int
+        lib.pt_unpack_tiles_rgb.argtypes = [vp, vp, C.c_uint64, u32, u32, u32, u32, vp]
         lib.pt_set_textures.restype = C.c_int
         lib.pt_set_textures.argtypes = [vp, vp, u32, vp, vp]
         lib.pt_update_rotations.restype = C.c_int
@@ -280,6 +284,13 @@ class Renderer:
     def accumulate(self, accum_ptr, radiance_ptr, n_pixels, frames_accumulated):
         """running mean of successive frames (device pointers), asynchronous on the context's stream"""
         self._check(self._lib.pt_accumulate(self._ctx, C.c_void_p(accum_ptr), C.c_void_p(radiance_ptr), n_pixels, frames_accumulated))
+
+    def pack_rgb(self, src_ptr, n_pixels, dst_ptr):
+        """device float4[n] -> device 3 floats per pixel (the 12-byte exchange format)"""
+        self._check(self._lib.pt_pack_rgb(self._ctx, C.c_void_p(src_ptr), n_pixels, C.c_void_p(dst_ptr)))
+
+    def unpack_tiles_rgb(self, packed_ptr, part_stride_px, n_parts, first0, run, stride, frame_ptr):
+        self._check(self._lib.pt_unpack_tiles_rgb(self._ctx, C.c_void_p(packed_ptr), part_stride_px, n_parts, first0, run, stride, C.c_void_p(frame_ptr)))
 
     def trace_rays(self, origins, directions, tmin=0.0, use_bvh=True):
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)

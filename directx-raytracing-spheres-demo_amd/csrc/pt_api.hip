@@ -412,9 +412,12 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     const uint32_t trav_threads = traverse_threads(c->lds_scene);
     const uint32_t fused_threads = c->lds_scene ? env_u32("PT_FUSED_THREADS", 512) : 256u;
     const uint32_t loop_threads = env_u32("PT_LOOP_THREADS", loop_is_main && c->lds_scene ? 512u : 256u);
-    // wavefront passes before the looping kernel (spp == 1).  Fused: the primary pass already traces the first bounce too
-    // (bounce_kernel kIters), so the looping kernel follows it directly: two launches per frame.
-    const size_t tail_after = env_u32("PT_TAIL_AFTER", split ? 3 : 0);
+    // Queue-fed passes before the looping kernel (spp == 1).  Fused, large frames: the primary pass also traces the first bounce
+    // in registers (bounce_kernel kInline2) and the looping kernel follows it directly -- two launches per frame.  It pays from
+    // about 2 M slots up (1080p: 0-5 %, 1440p: 4 %, 4K: 8 %); smaller frames are latency-bound and lose badly (1600x900: 0.124
+    // vs 0.089 ms, 960x540: 0.110 vs 0.062 ms), so they keep the separate bounce-1 pass.
+    const bool inline2 = !split && spp == 1 && pm.n_slots >= env_u32("PT_INLINE2_MIN_SLOTS", 2000000u);
+    const size_t tail_after = env_u32("PT_TAIL_AFTER", split ? 3 : (inline2 ? 0 : 1));
     const uint32_t tail_threshold = env_u32("PT_TAIL_THRESHOLD", 262144);  // queue size below which spp > 1 switches to it
 
     const bool timed = stats != nullptr;
@@ -481,7 +484,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
                 break;
             }
             PT_HIP(c, bracket(loop ? 3 : (primary ? 0 : 1), [&] {
-                return launch_bounce(sv, pm, fp, qin, qout, L.scratch, out, counts + k, counts + k + 1, fc, primary, loop, threads,
+                return launch_bounce(sv, pm, fp, qin, qout, L.scratch, out, counts + k, counts + k + 1, fc, primary, loop, inline2, threads,
                                      grid_for(items, threads, cap), L.stream);
             }));
             if (loop || last_possible) break;
@@ -947,12 +950,37 @@ PtStatus pt_unpack_tiles(PtContext* c, const void* gathered, uint32_t max_tiles_
     PT_HIP(c, hipSetDevice(c->device));
     const uint32_t ts = c->tile_size, w = c->gs.RenderSize[0], h = c->gs.RenderSize[1];
     PT_HIP(c, launch_unpack_tiles(static_cast<const float4*>(gathered), static_cast<float4*>(frame), w, h, ts, (w + ts - 1) / ts, 0, 1, c->world,
-                                  c->world, (uint64_t)max_tiles_per_rank * ts * ts, c->stream));
+                                  c->world, (uint64_t)max_tiles_per_rank * ts * ts, false, c->stream));
     return PT_OK;
 }
 
+static PtStatus unpack_ex(PtContext* c, const void* packed, uint64_t part_stride_px, uint32_t n_parts, uint32_t first0, uint32_t run,
+                          uint32_t stride, void* frame, bool rgb);
+
 PtStatus pt_unpack_tiles_ex(PtContext* c, const void* packed, uint64_t part_stride_px, uint32_t n_parts, uint32_t first0, uint32_t run,
                             uint32_t stride, void* frame)
+{
+    return unpack_ex(c, packed, part_stride_px, n_parts, first0, run, stride, frame, false);
+}
+
+PtStatus pt_unpack_tiles_rgb(PtContext* c, const void* packed, uint64_t part_stride_px, uint32_t n_parts, uint32_t first0, uint32_t run,
+                             uint32_t stride, void* frame)
+{
+    return unpack_ex(c, packed, part_stride_px, n_parts, first0, run, stride, frame, true);
+}
+
+PtStatus pt_pack_rgb(PtContext* c, const void* src, uint64_t n_pixels, void* dst)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!src || !dst) return fail(c, PT_ERR_INVALID_ARG, "pt_pack_rgb: null pointer");
+    if (n_pixels == 0) return PT_OK;
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, launch_pack_rgb(static_cast<const float4*>(src), static_cast<float*>(dst), n_pixels, c->stream));
+    return PT_OK;
+}
+
+static PtStatus unpack_ex(PtContext* c, const void* packed, uint64_t part_stride_px, uint32_t n_parts, uint32_t first0, uint32_t run,
+                          uint32_t stride, void* frame, bool rgb)
 {
     if (!c) return PT_ERR_INVALID_ARG;
     if (!packed || !frame || !c->gs_set) return fail(c, PT_ERR_INVALID_ARG, "pt_unpack_tiles_ex: null pointer or no constants");
@@ -964,7 +992,7 @@ PtStatus pt_unpack_tiles_ex(PtContext* c, const void* packed, uint64_t part_stri
         return fail(c, PT_ERR_INVALID_ARG, "pt_unpack_tiles_ex: part_stride_px smaller than one part's tiles");
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, launch_unpack_tiles(static_cast<const float4*>(packed), static_cast<float4*>(frame), w, h, ts, (w + ts - 1) / ts, first0, run, stride,
-                                  n_parts, part_stride_px, c->stream));
+                                  n_parts, part_stride_px, rgb, c->stream));
     return PT_OK;
 }
 

@@ -31,9 +31,10 @@ hipError_t launch_flush_counters(uint32_t* counts, uint32_t n_counts, unsigned l
                                  hipStream_t stream);
 hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const RayQueue& qout,
                          const Scratch& scratch, float4* out, const uint32_t* count_in, uint32_t* count_out, const FrameCounters& fc,
-                         bool primary, bool loop, uint32_t threads, uint32_t grid, hipStream_t stream);
+                         bool primary, bool loop, bool inline2, uint32_t threads, uint32_t grid, hipStream_t stream);
 hipError_t launch_unpack_tiles(const float4* packed, float4* frame, uint32_t w, uint32_t h, uint32_t ts, uint32_t tiles_x, uint32_t first0,
-                               uint32_t run, uint32_t stride, uint32_t n_parts, uint64_t part_stride, hipStream_t stream);
+                               uint32_t run, uint32_t stride, uint32_t n_parts, uint64_t part_stride, bool rgb, hipStream_t stream);
+hipError_t launch_pack_rgb(const float4* src, float* dst, uint64_t n, hipStream_t stream);
 
 hipError_t launch_di(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, float4* di, unsigned long long* ray_counter, uint32_t grid,
                      hipStream_t stream);

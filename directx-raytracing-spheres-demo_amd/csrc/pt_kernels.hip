@@ -638,7 +638,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(SceneView sv, PixelM
 // queue (wave64 ballot + prefix, one atomic per workgroup) -- one wavefront bounce per launch, 96 B of queue traffic
 // per ray and no hit stream.  kLoop = true: the lane keeps alternating trace and shade_step until its pixel is done
 // (the persistent "tail" form for small queues).
-template <bool kLds, typename StackT, bool kPrimary, bool kLoop, bool kMulti, bool kTex>
+template <bool kLds, typename StackT, bool kPrimary, bool kLoop, bool kMulti, bool kTex, bool kInline2>
 // 4 waves/SIMD (<= 128 VGPRs): two 512-thread workgroups per CU with the BVH in LDS (the unconstrained build takes 134
 // VGPRs for the primary variant and drops to 3 waves/SIMD: measured 171 -> 149 us for the two compacting passes at C2)
 __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void bounce_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue qin, RayQueue qout,
@@ -650,8 +650,10 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
     // ray and, in registers, the first bounce ray of the ~49 % of pixels that hit something): the ~1.0 M bounce-1 rays of a
     // 1080p frame then never travel through HBM (96 MB per frame) and the most latency-exposed pass of the frame (a
     // separate queue-fed bounce-1 launch, 63 % of its wave time in s_waitcnt) disappears; the half-empty waves cost less
-    // than that.  Measured on C2: 1 bounce 0.1165, 2 bounces 0.107, 3 bounces 0.116, 4 bounces 0.123 ms per frame.
-    constexpr uint32_t kIters = (kPrimary && !kLoop && !kMulti) ? 2u : 1u;
+    // than that.  Measured on C2: 1 bounce 0.1165, 2 bounces 0.107, 3 bounces 0.116, 4 bounces 0.123 ms per frame.  It only pays
+    // for large frames (kInline2, chosen by the host): a 640x384 share is latency-bound, and there the longer primary pass
+    // costs more than the bounce-1 launch it replaces (54 -> 64 us per frame with four frames in flight).
+    constexpr uint32_t kIters = (kPrimary && !kLoop && !kMulti && kInline2) ? 2u : 1u;
     extern __shared__ float4 smem[];
     __shared__ uint32_t s_wave_count[kFusedThreads / 64];
     __shared__ uint32_t s_block_base;
@@ -873,6 +875,9 @@ __global__ void brute_kernel(SceneView sv, const float* __restrict__ o, const fl
 // holds, in increasing tile order, the tiles t with first0 + i*run <= t % stride < first0 + (i+1)*run; consecutive parts
 // are part_stride float4 apart.  Pixels of tiles owned by none of the n_parts parts are left untouched (another call
 // with the other parts fills them).
+// kRgb: the parts hold 3 floats per pixel (pt_pack_rgb: alpha is 1 for every pixel of the frame, so it need not travel over the
+// links -- 25 % fewer bytes into the assembling GPU); part_stride is in pixels either way.
+template <bool kRgb>
 __global__ void unpack_tiles_kernel(const float4* __restrict__ packed, float4* __restrict__ frame, uint32_t w, uint32_t h, uint32_t ts,
                                     uint32_t tiles_x, uint32_t first0, uint32_t run, uint32_t stride, uint32_t n_parts, uint64_t part_stride)
 {
@@ -885,7 +890,22 @@ __global__ void unpack_tiles_kernel(const float4* __restrict__ packed, float4* _
         const uint32_t d = res - first0, part = d / run;
         if (part >= n_parts) continue;
         const uint32_t k = period * run + (d - part * run);
-        frame[p] = packed[(size_t)part * part_stride + (size_t)k * ts * ts + (y % ts) * ts + (x % ts)];
+        const size_t src = (size_t)part * part_stride + (size_t)k * ts * ts + (y % ts) * ts + (x % ts);
+        if (kRgb) {
+            const float* q = reinterpret_cast<const float*>(packed) + 3u * src;
+            frame[p] = make_float4(q[0], q[1], q[2], 1.0f);
+        } else {
+            frame[p] = packed[src];
+        }
+    }
+}
+
+// float4 (r, g, b, a) -> 3 floats per pixel, for the exchange buffers
+__global__ void pack_rgb_kernel(const float4* __restrict__ src, float* __restrict__ dst, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float4 v = src[i];
+        dst[3u * i] = v.x; dst[3u * i + 1u] = v.y; dst[3u * i + 2u] = v.z;
     }
 }
 
@@ -993,16 +1013,19 @@ hipError_t launch_tail(const SceneView& sv, const PixelMap& pm, const FrameParam
 
 hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const RayQueue& qout,
                          const Scratch& scratch, float4* out, const uint32_t* count_in, uint32_t* count_out, const FrameCounters& fc,
-                         bool primary, bool loop, uint32_t threads, uint32_t grid, hipStream_t stream)
+                         bool primary, bool loop, bool inline2, uint32_t threads, uint32_t grid, hipStream_t stream)
 {
     const bool small = sv.n_nodes < 32767u;
     const uint32_t elem = small ? 2u : 4u;
     const uint32_t lds = (sv.lds_scene ? scene_lds_bytes(sv.n_nodes, sv.n) : 0u) + threads * sv.stack_depth * elem;
-#define PT_BOUNCE5(L, T, P, LP, M, X)                                                                                      \
+#define PT_BOUNCE6(L, T, P, LP, M, X, I)                                                                                   \
     do {                                                                                                                    \
-        if (lds > 65536u) (void)hipFuncSetAttribute((const void*)bounce_kernel<L, T, P, LP, M, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((bounce_kernel<L, T, P, LP, M, X>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out, fc); \
+        if (lds > 65536u) (void)hipFuncSetAttribute((const void*)bounce_kernel<L, T, P, LP, M, X, I>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((bounce_kernel<L, T, P, LP, M, X, I>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out, fc); \
     } while (0)
+/* the in-register second bounce exists only for the 1-spp compacting primary pass */
+#define PT_BOUNCE5(L, T, P, LP, M, X)                                                                                      \
+    do { if (inline2 && P && !LP && !M) PT_BOUNCE6(L, T, P, LP, M, X, (P && !LP && !M)); else PT_BOUNCE6(L, T, P, LP, M, X, false); } while (0)
 #define PT_BOUNCE4(L, T, P, LP, M)                                                                                         \
     do { if (sv.tex_maps) PT_BOUNCE5(L, T, P, LP, M, true); else PT_BOUNCE5(L, T, P, LP, M, false); } while (0)
 #define PT_BOUNCE3(L, T, P, LP)                                                                                            \
@@ -1018,6 +1041,7 @@ hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FramePar
 #undef PT_BOUNCE3
 #undef PT_BOUNCE4
 #undef PT_BOUNCE5
+#undef PT_BOUNCE6
     return hipGetLastError();
 }
 
@@ -1051,12 +1075,13 @@ hipError_t launch_flush_counters(uint32_t* counts, uint32_t n_counts, unsigned l
 }
 
 hipError_t launch_unpack_tiles(const float4* packed, float4* frame, uint32_t w, uint32_t h, uint32_t ts, uint32_t tiles_x, uint32_t first0,
-                               uint32_t run, uint32_t stride, uint32_t n_parts, uint64_t part_stride,
+                               uint32_t run, uint32_t stride, uint32_t n_parts, uint64_t part_stride, bool rgb,
                                hipStream_t stream)
 {
     const uint32_t n = w * h;
     const uint32_t grid = (n + 255u) / 256u < 4096u ? (n + 255u) / 256u : 4096u;
-    hipLaunchKernelGGL(unpack_tiles_kernel, dim3(grid), dim3(256), 0, stream, packed, frame, w, h, ts, tiles_x, first0, run, stride, n_parts, part_stride);
+    if (rgb) hipLaunchKernelGGL(unpack_tiles_kernel<true>, dim3(grid), dim3(256), 0, stream, packed, frame, w, h, ts, tiles_x, first0, run, stride, n_parts, part_stride);
+    else hipLaunchKernelGGL(unpack_tiles_kernel<false>, dim3(grid), dim3(256), 0, stream, packed, frame, w, h, ts, tiles_x, first0, run, stride, n_parts, part_stride);
     return hipGetLastError();
 }
 
@@ -1076,6 +1101,13 @@ hipError_t launch_di(const SceneView& sv, const PixelMap& pm, const FrameParams&
     else { if (small) PT_DI(false, uint16_t); else PT_DI(false, uint32_t); }
 #undef PT_DI
 #undef PT_DI2
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_rgb(const float4* src, float* dst, uint64_t n, hipStream_t stream)
+{
+    const uint64_t blocks = (n + 255u) / 256u;
+    hipLaunchKernelGGL(pack_rgb_kernel, dim3((uint32_t)(blocks < 8192u ? (blocks ? blocks : 1u) : 8192u)), dim3(256), 0, stream, src, dst, n);
     return hipGetLastError();
 }
 

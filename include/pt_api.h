@@ -157,6 +157,12 @@ uint32_t pt_tiles_count_ex(PtContext *ctx, uint32_t first, uint32_t run, uint32_
  * by one call for the root's own range and one for the gathered ranges. */
 PtStatus pt_unpack_tiles_ex(PtContext *ctx, const void *packed_device, uint64_t part_stride_px, uint32_t n_parts,
                             uint32_t first0, uint32_t run, uint32_t stride, void *frame_device);
+/* RGB exchange: every pixel of a frame has alpha 1, so the buffers that cross the links can carry 12 instead of 16 bytes
+ * per pixel.  pt_pack_rgb copies n_pixels float4 (packed tiles, any number of frames) to 3 floats per pixel;
+ * pt_unpack_tiles_rgb is pt_unpack_tiles_ex for such parts (part_stride_px still counts pixels) and writes alpha = 1. */
+PtStatus pt_pack_rgb(PtContext *ctx, const void *src_device, uint64_t n_pixels, void *dst_device);
+PtStatus pt_unpack_tiles_rgb(PtContext *ctx, const void *packed_device, uint64_t part_stride_px, uint32_t n_parts,
+                             uint32_t first0, uint32_t run, uint32_t stride, void *frame_device);
 
 /* Row N1 -- textured spheres: EvaluateMaterial's texture branches + normal mapping (Shaders/ShadingHelpers.hlsli:53-103,
  * 161-235) over analytic sphere UVs / tangents (csrc/pt_texture.h).  Replaces the texture part of Scene::Load

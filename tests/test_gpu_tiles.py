@@ -85,6 +85,16 @@ def test_weighted_partition_invariance(dxrs, host, renderer, w, h, world, weight
     if weight:
         tiles.unpack_ranges(ref, list(others.cpu().numpy().reshape(world - 1, -1, ts2, 4)), root[1], 1, root[2])
     assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    if weight:
+        # the 12-byte exchange format: pack the gathered parts to 3 floats per pixel, un-swizzle with alpha = 1 -> same frame
+        rgb = torch.zeros((others.shape[0], others.shape[1], 3), dtype=torch.float32, device="cuda")
+        renderer.pack_rgb(others.data_ptr(), others.shape[0] * others.shape[1], rgb.data_ptr())
+        frame2 = torch.full((h, w, 4), -1.0, dtype=torch.float32, device="cuda")
+        renderer.unpack_tiles_ex(own.data_ptr(), 0, 1, root[0], root[1], root[2], frame2.data_ptr())
+        renderer.unpack_tiles_rgb(rgb.data_ptr(), others.shape[1], world - 1, root[1], 1, root[2], frame2.data_ptr())
+        renderer.synchronize()
+        assert np.array_equal(rgb.cpu().numpy(), others.cpu().numpy()[..., :3])
+        assert np.array_equal(frame2.cpu().numpy().view(np.uint32), out.view(np.uint32))
     with pytest.raises(RuntimeError):
         renderer.set_partition_ex(3, 2, 4)  # first + run > stride
     renderer.set_partition(0, 1)

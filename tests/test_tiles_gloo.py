@@ -131,9 +131,17 @@ class _OracleOps:
             self.cache[k] = self.oracle.render(self.spheres, self.materials, self.sd, self.cams[k % 8], gs, threads=2)[0]
         return self.cache[k]
 
-    def alloc(self, n_px):
+    def alloc(self, n_px, channels=4):
         import torch
-        return torch.zeros((n_px, 4), dtype=torch.float32)
+        return torch.zeros((n_px, channels), dtype=torch.float32)
+
+    def pack_rgb(self, src, n_px, dst):
+        dst[:n_px] = src[:n_px, :3]
+
+    def unpack_rgb(self, packed, offset_px, part_stride_px, n_parts, first0, run, stride, frame):
+        import torch
+        rgba = torch.cat([packed, torch.ones((packed.shape[0], 1), dtype=torch.float32)], 1)
+        self.unpack(rgba, offset_px, part_stride_px, n_parts, first0, run, stride, frame)
 
     def set_range(self, first, run, stride):
         self.range = (first, run, stride)
@@ -169,8 +177,13 @@ def _exchange_worker(rank, world, port, w, h, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ops = _OracleOps(dxrs_amd, load_oracle(), dxrs_amd.load_host(), w, h)
     batch = 3
-    ex = TileExchange(ops, w, h, rank, world, batch)
     results = {}
+    ex_plain = TileExchange(ops, w, h, rank, world, batch, rgb=False)  # float4 records on the wire
+    ex = TileExchange(ops, w, h, rank, world, batch)                    # default: 12 bytes per pixel on the wire
+    for k in range(batch):
+        ex_plain.submit(k)
+    if rank == 0:
+        results["plain"] = np.stack([f.numpy().reshape(h, w, 4).copy() for f in ex_plain.frames])
     for weight in (1, 2, 5, 0):
         ex.configure(weight)
         got = []
@@ -196,6 +209,7 @@ def _exchange_worker(rank, world, port, w, h, out_path):
     assert chosen == 2 and ex.root_weight == 2
     if rank == 0:
         ref = np.stack([ops.full(k) for k in range(7)])
+        assert np.array_equal(results["plain"].view(np.uint32), ref[:3].view(np.uint32))
         np.save(out_path, np.stack([results[wt] for wt in (1, 2, 5, 0)] + [ref]))
     dist.barrier()
     dist.destroy_process_group()
