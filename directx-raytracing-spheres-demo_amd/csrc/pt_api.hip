@@ -400,7 +400,8 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     // Persistent workgroups: with the BVH staged into LDS per workgroup, 2 per CU (= the 4 waves/SIMD the kernel is built
     // for) amortise the 37 KB staging over ~4 batches of rays at 1080p / 1 spp (0.121 -> 0.116 ms per frame); with spp > 1
     // the passes are long and uneven, and more, shorter workgroups balance better (C3: 6.77 vs 6.89 ms).
-    const uint32_t trav_cap = c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", spp == 1 && c->lds_scene ? 2 : 8);
+    // (... from about 1.5 M slots: below that 8 per CU is 4-10 % faster)
+    const uint32_t trav_cap = c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", spp == 1 && c->lds_scene && pm.n_slots >= 1500000u ? 2 : 8);
     const uint32_t trav_cap_wide = c->num_cus * 8u;
     const uint32_t shade_cap = c->num_cus * env_u32("PT_SHADE_BLOCKS_PER_CU", 16);
     // the looping pass: small queues at 1 spp (256 threads, up to 8 workgroups per CU); at spp > 1 of the fused schedule it
@@ -413,10 +414,9 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     const uint32_t fused_threads = c->lds_scene ? env_u32("PT_FUSED_THREADS", 512) : 256u;
     const uint32_t loop_threads = env_u32("PT_LOOP_THREADS", loop_is_main && c->lds_scene ? 512u : 256u);
     // Queue-fed passes before the looping kernel (spp == 1).  Fused, large frames: the primary pass also traces the first bounce
-    // in registers (bounce_kernel kInline2) and the looping kernel follows it directly -- two launches per frame.  It pays from
-    // about 2 M slots up (1080p: 0-5 %, 1440p: 4 %, 4K: 8 %); smaller frames are latency-bound and lose badly (1600x900: 0.124
-    // vs 0.089 ms, 960x540: 0.110 vs 0.062 ms), so they keep the separate bounce-1 pass.
-    const bool inline2 = !split && spp == 1 && pm.n_slots >= env_u32("PT_INLINE2_MIN_SLOTS", 2000000u);
+    // in registers (bounce_kernel kInline2) and the looping kernel follows it directly -- two launches per frame: 4-10 % faster at
+    // every frame size from 256x256 to 4K (PT_INLINE2_MIN_SLOTS switches it off below a slot count, for A/B runs).
+    const bool inline2 = !split && spp == 1 && pm.n_slots >= env_u32("PT_INLINE2_MIN_SLOTS", 0u);
     const size_t tail_after = env_u32("PT_TAIL_AFTER", split ? 3 : (inline2 ? 0 : 1));
     const uint32_t tail_threshold = env_u32("PT_TAIL_THRESHOLD", 262144);  // queue size below which spp > 1 switches to it
 

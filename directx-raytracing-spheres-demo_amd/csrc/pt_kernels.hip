@@ -33,6 +33,23 @@ __device__ __forceinline__ float slab_rcp(float d)
     return fast_rcp(__builtin_fabsf(d) < kTiny ? __builtin_copysignf(kTiny, d) : d);
 }
 
+// Adds the sum of `v` over the workgroup to *counter with ONE atomic (wave shuffle -> LDS -> thread 0).  Same-address
+// device-scope atomics from all 8 XCDs serialise; one per wave has been measured to dominate short kernels.
+__device__ __forceinline__ void block_atomic_add(unsigned long long* counter, unsigned long long v)
+{
+    __shared__ unsigned long long s_part[16];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long sum = 0;
+        for (uint32_t w = 0; w < (blockDim.x + 63u) / 64u; w++) sum += s_part[w];
+        if (sum) atomicAdd(counter, sum);
+    }
+}
+
 // Called by every thread of ONE block: fold a finished frame's counters (queue sizes 1..n + its tail counter) into
 // the running totals and leave them zeroed.
 __device__ __forceinline__ void fold_counters(uint32_t* __restrict__ counts, uint32_t n_counts, unsigned long long* __restrict__ tail,
@@ -625,11 +642,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(SceneView sv, PixelM
             my_rays++;  // rays spawned inside the tail (the input queue's rays are already in counts[])
         }
     }
-    // wave-reduce the ray count, one atomic per wave
-    unsigned long long total = my_rays;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
-    if (lane_id() == 0 && total) atomicAdd(tail_rays, total);
+    block_atomic_add(tail_rays, my_rays);
 }
 
 // ------------------------------------------------------------------------------------------------ fused bounce
@@ -650,9 +663,8 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
     // ray and, in registers, the first bounce ray of the ~49 % of pixels that hit something): the ~1.0 M bounce-1 rays of a
     // 1080p frame then never travel through HBM (96 MB per frame) and the most latency-exposed pass of the frame (a
     // separate queue-fed bounce-1 launch, 63 % of its wave time in s_waitcnt) disappears; the half-empty waves cost less
-    // than that.  Measured on C2: 1 bounce 0.1165, 2 bounces 0.107, 3 bounces 0.116, 4 bounces 0.123 ms per frame.  It only pays
-    // for large frames (kInline2, chosen by the host): a 640x384 share is latency-bound, and there the longer primary pass
-    // costs more than the bounce-1 launch it replaces (54 -> 64 us per frame with four frames in flight).
+    // than that.  Measured on C2: 1 bounce 0.1165, 2 bounces 0.107, 3 bounces 0.116, 4 bounces 0.123 ms per frame (kInline2 is
+    // the host's switch; it is on for every 1-spp frame of the fused schedule).
     constexpr uint32_t kIters = (kPrimary && !kLoop && !kMulti && kInline2) ? 2u : 1u;
     extern __shared__ float4 smem[];
     __shared__ uint32_t s_wave_count[kFusedThreads / 64];
@@ -736,12 +748,21 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
         }
     }
     if (kLoop || kIters > 1u) {
+        // rays traced in registers: wave reduce, then ONE atomic pair per workgroup (same-address device-scope atomics from
+        // 8 XCDs serialise: one per wave made the non-persistent form of this kernel three times slower)
         unsigned long long total = my_rays;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
-        if (lane == 0 && total) {
-            atomicAdd(fc.tail_rays, total);
-            if (!kLoop) atomicAdd(fc.totals + 4, total);  // running count of the rays a primary pass traced in registers (statistics)
+        __syncthreads();  // s_wave_count is free again
+        if (lane == 0) s_wave_count[wave] = (uint32_t)total;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long sum = 0;
+            for (uint32_t w = 0; w < (blockDim.x >> 6); w++) sum += s_wave_count[w];
+            if (sum) {
+                atomicAdd(fc.tail_rays, sum);
+                if (!kLoop) atomicAdd(fc.totals + 4, sum);  // running count of the rays a primary pass traced in registers (statistics)
+            }
         }
     }
 }
@@ -811,10 +832,7 @@ __global__ __launch_bounds__(kTraverseThreads) void di_kernel(SceneView sv, Pixe
             est = make_f3(0.f, 0.f, 0.f);  // NaN / inf / negative estimates count as no light
         di[slot] = make_float4(est.x, est.y, est.z, 0.0f);
     }
-    unsigned long long total = my_rays;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
-    if (lane_id() == 0 && total) atomicAdd(ray_counter, total);
+    block_atomic_add(ray_counter, my_rays);
 }
 
 // ------------------------------------------------------------------------------------------------ test hooks
