@@ -273,8 +273,9 @@ static hipError_t launch_refit(const float4* sorted, uint32_t n, PtBvhNode* node
     return hipGetLastError();
 }
 
-__global__ void depth_kernel(const PtBvhNode* __restrict__ nodes, const int* __restrict__ leaf_parent, int n, uint32_t* __restrict__ hdr)
+__global__ __launch_bounds__(256) void depth_kernel(const PtBvhNode* __restrict__ nodes, const int* __restrict__ leaf_parent, int n, uint32_t* __restrict__ hdr)
 {
+    __shared__ uint32_t s_best[4];
     uint32_t best = 0;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         uint32_t d = 0;
@@ -283,7 +284,12 @@ __global__ void depth_kernel(const PtBvhNode* __restrict__ nodes, const int* __r
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) best = max(best, (uint32_t)__shfl_down(best, off, 64));
-    if ((threadIdx.x & 63u) == 0 && best) atomicMax(&hdr[12], best);
+    if ((threadIdx.x & 63u) == 0) s_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one atomic per workgroup (same-address atomics from every wave serialise)
+        for (uint32_t w = 1; w < (blockDim.x >> 6); w++) best = max(best, s_best[w]);
+        if (best) atomicMax(&hdr[12], best);
+    }
 }
 
 }  // namespace
