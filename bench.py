@@ -42,6 +42,8 @@ def main():
                          "frames' start; 0 = auto (3 on one GPU, 4 when the frame is split over several)")
     ap.add_argument("--animate", action="store_true",
                     help="demo scene in motion (closed-form springs + Moon orbit, 1/60 s per frame): per-frame sphere upload + LBVH refit inside the timed region")
+    ap.add_argument("--env-map", action="store_true",
+                    help="light the demo scene with the lat-long environment map (MyScene.ixx:94-95; procedural HDR stand-in) instead of the sky")
     ap.add_argument("--textures", action="store_true",
                     help="demo scene with its textured objects (row N1: Alien-Metal, Moon, Earth; procedural stand-ins for the reference's image files)")
     ap.add_argument("--di", action="store_true", help="IsDIEnabled = 1 (row N4): sphere-light direct illumination pass before the bounce passes")
@@ -90,14 +92,17 @@ def main():
         args.frames_in_flight = 4 if (world > 1 or args.force_tiles) else 3
     nbuf = args.frames_in_flight
     r = dxrs_amd.Renderer(device=local_rank, stream=stream, frames_in_flight=nbuf)
+    tex = None
+    if args.textures or args.env_map:
+        if args.scene != "demo":
+            raise SystemExit("--textures / --env-map are defined for the demo scene")
+        tex, sd_env = host.demo_textures(0, 0.0, textured=args.textures, environment_map=args.env_map, return_scene_data=True)
+        if args.env_map:
+            sd = sd_env  # names the environment map in the texture table
     accel = r.set_scene(spheres, materials, sd)
     first_build_ms = float(accel.build_ms)   # includes the one-time code-object load of the sort kernels
     accel = r.build_accel()                  # steady-state full rebuild (what a per-frame TLAS rebuild would cost)
-    tex = None
-    if args.textures:
-        if args.scene != "demo":
-            raise SystemExit("--textures is defined for the demo scene")
-        tex = host.demo_textures(0, 0.0)
+    if tex is not None:
         r.set_textures(tex)
     gs = graphics_settings(w, h, frame_index=0, bounces=args.bounces, spp=args.spp, di=args.di)
     r.set_constants(gs)
@@ -212,7 +217,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.scene} sphere scene (seed {1 if args.scene == 'procedural' else 0}, {len(spheres)} spheres), {w}x{h}, {args.spp} spp, {args.bounces} bounces, RR on, sky env"
+                "workload": f"{args.scene} sphere scene (seed {1 if args.scene == 'procedural' else 0}, {len(spheres)} spheres), {w}x{h}, {args.spp} spp, {args.bounces} bounces, RR on, " + ("lat-long HDR environment map (procedural stand-in, 1024x512)" if args.env_map else "sky env")
                             + (", textured (Alien-Metal, Moon, Earth; procedural stand-in images)" if args.textures else "")
                             + (", sphere-light direct illumination (IsDIEnabled)" if args.di else "")
                             + (f", 32x32 tiles interleaved over {world} GPU(s) + RCCL gather to rank 0" if tiled else ""),
@@ -264,7 +269,7 @@ def main():
         traffic = None
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the guide prescribes)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pmc.get("workload") == f"{args.scene}-{w}x{h}-{args.spp}spp-{args.bounces}b" and not split and not args.di and not args.textures:
+            if pmc.get("workload") == f"{args.scene}-{w}x{h}-{args.spp}spp-{args.bounces}b" and not split and not args.di and not args.textures and not args.env_map:
                 key = "bounce<loop>" if "loop" in name else "bounce<wavefront>"
                 traffic = pmc[key]["hbm_bytes_per_launch"]
         except Exception:
@@ -297,7 +302,7 @@ def main():
         # on 256 CUs x 4 SIMDs at the measured 2.35 GHz (tools/experiments/clock.hip)
         valu = None
         try:
-            if pmc.get("workload") == f"{args.scene}-{w}x{h}-{args.spp}spp-{args.bounces}b" and not split and not args.textures and not tiled and not args.di:
+            if pmc.get("workload") == f"{args.scene}-{w}x{h}-{args.spp}spp-{args.bounces}b" and not split and not args.textures and not args.env_map and not tiled and not args.di:
                 sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))["kernels"]
                 per_frame = sum(k["valu_insts_per_launch"] for k in sq.values())
                 bound_ms = per_frame * 4 / 1024 / 2.35e9 * 1e3

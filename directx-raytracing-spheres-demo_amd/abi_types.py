@@ -54,7 +54,7 @@ class PtTextureMapInfo(C.Structure):
 
 TEXTURE_MAP_BASE_COLOR, TEXTURE_MAP_EMISSIVE_COLOR, TEXTURE_MAP_METALLIC, TEXTURE_MAP_ROUGHNESS = 0, 1, 2, 3
 TEXTURE_MAP_METALLIC_ROUGHNESS, TEXTURE_MAP_TRANSMISSION, TEXTURE_MAP_NORMAL, TEXTURE_MAP_COUNT = 4, 5, 6, 7
-TEXTURE_RGBA8_UNORM, TEXTURE_RGBA8_UNORM_SRGB = 0, 1
+TEXTURE_RGBA8_UNORM, TEXTURE_RGBA8_UNORM_SRGB, TEXTURE_RGBA32_FLOAT = 0, 1, 2
 
 
 class PtObjectTextures(C.Structure):

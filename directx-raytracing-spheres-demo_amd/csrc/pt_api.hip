@@ -244,6 +244,9 @@ SceneView make_scene_view(const PtContext* c, const Lane* L = nullptr)
     sv.lds_scene = c->lds_scene ? 1u : 0u;
     for (int i = 0; i < 4; i++) sv.env[i] = c->sd.EnvironmentLightColor[i];
     if (c->has_textures) { sv.tex = c->d_tex; sv.tex_maps = c->d_tex_maps; sv.rot = c->d_rot; }
+    sv.env_tex = c->sd.EnvironmentLightTextureDescriptor;  // ~0u == kNoTexture; render_common has checked it against the table
+    for (int r = 0; r < 3; r++)
+        for (int k = 0; k < 3; k++) sv.env_xf[3 * r + k] = c->sd.EnvironmentLightTransform[4 * r + k];
     sv.lights = c->d_lights; sv.n_lights = c->n_lights;
     return sv;
 }
@@ -345,6 +348,8 @@ void sum_events(PtContext* c, size_t begin, size_t end, PtStats* stats)
 PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, float4* out, PtStats* stats)
 {
     const uint32_t bounces = c->gs.Bounces, spp = c->gs.SamplesPerPixel;
+    if (c->sd.EnvironmentLightTextureDescriptor != ~0u && (!c->has_textures || c->sd.EnvironmentLightTextureDescriptor >= c->d_tex_images.size()))
+        return fail(c, PT_ERR_STATE, "SceneData.EnvironmentLightTextureDescriptor names a texture the table of pt_set_textures does not hold (call pt_set_textures after pt_set_scene)");
     const size_t max_iters = (size_t)spp * bounces + 1;  // passes if everything ran as wavefront
     const size_t wf_cap = spp > 1 ? max_iters : std::min<size_t>(max_iters, 64);
     // LDS-resident BVH: fused trace+shade passes (traversal is cheap, the hit stream is pure overhead).  BVH in global
@@ -667,8 +672,8 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
     if (!c) return PT_ERR_INVALID_ARG;
     if (!spheres || !materials || !sd || n == 0) return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: null pointer or n == 0");
     if (n > (1u << 30)) return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: too many spheres");
-    if (sd->EnvironmentLightTextureDescriptor != ~0u)
-        return fail(c, PT_ERR_UNSUPPORTED, "environment light textures are not supported (EnvironmentLightTextureDescriptor must be ~0u)");
+    if (sd->EnvironmentLightTextureDescriptor != ~0u && sd->IsEnvironmentLightTextureCubeMap)
+        return fail(c, PT_ERR_UNSUPPORTED, "cube-map environment lights are not supported (lat-long maps only: IsEnvironmentLightTextureCubeMap must be 0)");
     for (uint32_t i = 0; i < n; i++)
         if (!(spheres[i].r > 0.0f) || !std::isfinite(spheres[i].r) || !std::isfinite(spheres[i].cx) || !std::isfinite(spheres[i].cy) || !std::isfinite(spheres[i].cz))
             return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: sphere " + std::to_string(i) + " has a non-finite centre or non-positive radius");
@@ -1004,19 +1009,20 @@ PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_tex
     PT_HIP(c, sync_all(c));
     free_textures(c);
     if (n_textures == 0) return PT_OK;
-    if (!textures || !object_textures) return fail(c, PT_ERR_INVALID_ARG, "pt_set_textures: null pointer");
+    if (!textures) return fail(c, PT_ERR_INVALID_ARG, "pt_set_textures: null pointer");
     const uint32_t n = c->n;
     // validate before touching the device
     for (uint32_t t = 0; t < n_textures; t++) {
         const PtTexture& tx = textures[t];
-        if (!tx.Pixels || tx.Width == 0 || tx.Height == 0 || tx.Width > 16384 || tx.Height > 16384 || tx.Format > PT_TEXTURE_RGBA8_UNORM_SRGB)
+        if (!tx.Pixels || tx.Width == 0 || tx.Height == 0 || tx.Width > 16384 || tx.Height > 16384 || tx.Format > PT_TEXTURE_RGBA32_FLOAT)
             return fail(c, PT_ERR_INVALID_ARG, "pt_set_textures: bad texture (null pixels, size outside 1..16384, or unknown format)");
     }
     std::vector<uint32_t> maps((size_t)n * 8u);
     for (uint32_t i = 0; i < n; i++) {
         uint32_t any = 0;
         for (uint32_t k = 0; k < PT_TEXTURE_MAP_COUNT; k++) {
-            const PtTextureMapInfo& mi = object_textures[i].Maps[k];
+            const PtTextureMapInfo none{~0u, 0u, 0u, 0u};
+            const PtTextureMapInfo& mi = object_textures ? object_textures[i].Maps[k] : none;
             if (mi.Descriptor != ~0u) {
                 if (mi.Descriptor >= n_textures) return fail(c, PT_ERR_INVALID_ARG, "pt_set_textures: Descriptor out of range");
                 if (mi.TextureCoordinateIndex != 0) return fail(c, PT_ERR_UNSUPPORTED, "pt_set_textures: spheres have one texture-coordinate set (index 0)");
@@ -1035,13 +1041,17 @@ PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_tex
     for (uint32_t t = 0; t < n_textures; t++) {
         const PtTexture& tx = textures[t];
         const size_t count = (size_t)tx.Width * tx.Height;
-        texels.resize(count);
-        const uint8_t* px = static_cast<const uint8_t*>(tx.Pixels);
-        const float* lut = tx.Format == PT_TEXTURE_RGBA8_UNORM_SRGB ? srgb_lut : unorm_lut;
-        for (size_t i = 0; i < count; i++)
-            texels[i] = make_float4(lut[px[4 * i]], lut[px[4 * i + 1]], lut[px[4 * i + 2]], unorm_lut[px[4 * i + 3]]);
+        const void* src = tx.Pixels;  // RGBA32_FLOAT is the device layout already
+        if (tx.Format != PT_TEXTURE_RGBA32_FLOAT) {
+            texels.resize(count);
+            const uint8_t* px = static_cast<const uint8_t*>(tx.Pixels);
+            const float* lut = tx.Format == PT_TEXTURE_RGBA8_UNORM_SRGB ? srgb_lut : unorm_lut;
+            for (size_t i = 0; i < count; i++)
+                texels[i] = make_float4(lut[px[4 * i]], lut[px[4 * i + 1]], lut[px[4 * i + 2]], unorm_lut[px[4 * i + 3]]);
+            src = texels.data();
+        }
         PT_HIP(c, hipMalloc(&c->d_tex_images[t], count * sizeof(float4)));
-        PT_HIP(c, hipMemcpy(c->d_tex_images[t], texels.data(), count * sizeof(float4), hipMemcpyHostToDevice));
+        PT_HIP(c, hipMemcpy(c->d_tex_images[t], src, count * sizeof(float4), hipMemcpyHostToDevice));
         views[t].texels = c->d_tex_images[t]; views[t].w = tx.Width; views[t].h = tx.Height;
     }
     PT_HIP(c, hipMalloc(&c->d_tex, n_textures * sizeof(TexView)));

@@ -97,6 +97,25 @@ PT_HD void sample_bilinear(const TexView& tv, f2 uv, float out[4])
     out[3] = lerp1(lerp1(c00.w, c10.w, fx), lerp1(c01.w, c11.w, fx), fy);
 }
 
+// GetEnvironmentLightColor's texture branch (ShadingHelpers.hlsli:13-24) for a lat-long map: rotate by the upper 3x3 of
+// EnvironmentLightTransform (Geometry::RotateVector = mul(M, v)), normalise, Math::ToLatLongCoordinate (Math.hlsli:29-33:
+// u = (1 + atan2(x, z) / pi) / 2, v = acos(y) / pi), level-0 sample.
+PT_HD f2 latlong_uv(f3 d)
+{
+    f2 uv;
+    uv.x = pt_fma(atan2_spec(d.x, d.z), 0.15915494309189533577f, 0.5f);
+    uv.y = atan2_spec(pt_sqrt(pt_max(pt_fma(-d.y, d.y, 1.0f), 0.0f)), d.y) * 0.31830988618379067154f;
+    return uv;
+}
+
+PT_HD f3 environment_texture(const TexView& tv, const float* m, f3 d)
+{
+    const f3 r = normalize(make_f3(dot(make_f3(m[0], m[1], m[2]), d), dot(make_f3(m[3], m[4], m[5]), d), dot(make_f3(m[6], m[7], m[8]), d)));
+    float s[4];
+    sample_bilinear(tv, latlong_uv(r), s);
+    return make_f3(s[0], s[1], s[2]);
+}
+
 // Geometry::UnpackLocalNormal (MathLib, un-vendored; recollection): xy = s * 255/127 - 1, z = Sqrt01(1 - |xy|^2)
 PT_HD f3 unpack_local_normal(float sx, float sy)
 {

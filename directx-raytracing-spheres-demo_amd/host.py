@@ -53,31 +53,40 @@ class HostLib:
             raise ValueError(f"pth_scene_at_time failed ({rc})")
         return spheres
 
-    def demo_textures(self, seed=0, time=0.0):
+    def demo_textures(self, seed=0, time=0.0, textured=True, environment_map=False, return_scene_data=False):
         """TextureSet of the demo scene's textured objects (Alien-Metal, Moon, Earth: Source/MyScene.ixx:161-166, 285-295)
-        at simulation time `time`, as the C++ host mirror builds it (MySceneDesc(seed, textured=true); procedural stand-ins
-        for the reference's image files unless a loader is installed on the C++ side)."""
-        from .abi_types import TEXTURE_MAP_COUNT, TEXTURE_RGBA8_UNORM_SRGB, PtObjectTextures
+        at simulation time `time`, as the C++ host mirror builds it (MySceneDesc(seed, textured, environmentMap); procedural
+        stand-ins for the reference's image files unless a loader is installed on the C++ side).  environment_map adds the
+        lat-long environment light (MyScene.ixx:94-95) to the table; return_scene_data -> (TextureSet, PtSceneData), the
+        SceneData that names it."""
+        from .abi_types import TEXTURE_MAP_COUNT, TEXTURE_RGBA8_UNORM_SRGB, TEXTURE_RGBA32_FLOAT, PtObjectTextures, PtSceneData
         from .textures import TextureSet
-        self.lib.pth_demo_textures.restype = C.c_int
-        self.lib.pth_demo_textures.argtypes = [C.c_uint32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        fn = self.lib.pth_demo_textures_ex
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_uint32, C.c_double, C.c_uint32] + [C.c_void_p] * 8
+        flags = (1 if textured else 0) | (2 if environment_map else 0)
         nt, no, nb = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
-        self.lib.pth_demo_textures(seed, time, C.byref(nt), C.byref(no), C.byref(nb), None, None, None, None)
+        sd = PtSceneData()
+        fn(seed, time, flags, C.byref(nt), C.byref(no), C.byref(nb), None, None, None, None, None)
         info = np.zeros((nt.value, 4), dtype=np.uint32)
         pixels = np.zeros(nb.value, dtype=np.uint8)
         obj = (PtObjectTextures * no.value)()
         rot = np.zeros((no.value, 4), dtype=np.float32)
-        rc = self.lib.pth_demo_textures(seed, time, C.byref(nt), C.byref(no), C.byref(nb), info.ctypes.data, pixels.ctypes.data, C.addressof(obj), rot.ctypes.data)
+        rc = fn(seed, time, flags, C.byref(nt), C.byref(no), C.byref(nb), info.ctypes.data, pixels.ctypes.data, C.addressof(obj), rot.ctypes.data, C.addressof(sd))
         if rc:
-            raise ValueError(f"pth_demo_textures failed ({rc})")
+            raise ValueError(f"pth_demo_textures_ex failed ({rc})")
         ts = TextureSet(no.value)
         for (w, h, fmt, off) in info:
-            ts.add_image(pixels[off:off + int(w) * int(h) * 4].reshape(int(h), int(w), 4).copy(), srgb=fmt == TEXTURE_RGBA8_UNORM_SRGB)
+            w, h, off = int(w), int(h), int(off)
+            if fmt == TEXTURE_RGBA32_FLOAT:
+                ts.add_hdr_image(pixels[off:off + w * h * 16].view(np.float32).reshape(h, w, 4).copy())
+            else:
+                ts.add_image(pixels[off:off + w * h * 4].reshape(h, w, 4).copy(), srgb=fmt == TEXTURE_RGBA8_UNORM_SRGB)
         for i in range(no.value):
             for k in range(TEXTURE_MAP_COUNT):
                 ts.maps[i, k] = obj[i].Maps[k].Descriptor
         ts.rotations[:] = rot
-        return ts
+        return (ts, sd) if return_scene_data else ts
 
     def camera(self, width, height, position=(0.0, 0.0, -15.0), look_at=None, hfov=math.pi / 2, jitter=True, jitter_index=0, jitter_count=8):
         """Demo camera (MyScene.ixx:90; HFOV 90 deg, MyAppData.h:177); jitter = Halton2D(index + 1) - 0.5 cycling mod 8."""

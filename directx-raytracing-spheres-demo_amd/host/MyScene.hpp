@@ -1,7 +1,7 @@
 // MyScene.hpp -- host mirror of the demo scene of Source/MyScene.ixx:52-303 at t = 0,
 // plus the two benchmark scenes of SURVEY 8d that are derived from it (C1: 16 spheres, C5: 2^20 procedural).
-// Textures are a "next" row; the environment EXR is a missing LFS blob, so the environment
-// is the procedural sky (Scene.ixx:65, ShadingHelpers.hlsli:25-29).
+// The environment EXR is a missing LFS blob, so by default the environment is the procedural sky (Scene.ixx:65,
+// ShadingHelpers.hlsli:25-29); MySceneDesc's `environmentMap` asks for the lat-long map the reference names.
 #pragma once
 
 #include <cmath>
@@ -131,10 +131,15 @@ inline RenderObjectDesc Star()  // MyScene.ixx:258-267: the mirror "ground"
 // The demo default scene.  The reference seeds from random_device; the build takes a seed.
 // `textured` = false is the benchmark configuration of SURVEY 8d ("textures off"); true attaches the texture files the
 // reference names for Alien-Metal, Moon and Earth (MyScene.ixx:161-166, 285-295) -- resolved by the Scene's texture loader.
+// `environmentMap` = true adds the reference's lat-long environment light (MyScene.ixx:94-95: yaw pi, 141_hdrmaps_com_free.exr).
 struct MySceneDesc : SceneDesc {
-    explicit MySceneDesc(unsigned seed = 0, bool textured = false)
+    explicit MySceneDesc(unsigned seed = 0, bool textured = false, bool environmentMap = false)
     {
         Camera.Position.z = -15;  // MyScene.ixx:90
+        if (environmentMap) {
+            EnvironmentLight.Rotation = Quaternion::CreateFromYawPitchRoll(3.14159265358979323846f, 0, 0);
+            EnvironmentLight.Texture = "Assets/Textures/141_hdrmaps_com_free.exr";
+        }
         detail::AddHeroes(*this);
         detail::AddGrid(*this, seed, ~size_t(0));
         RenderObjects.emplace_back(detail::Moon());
@@ -167,7 +172,11 @@ struct MySceneDesc : SceneDesc {
 //   * Moon: circular orbit of period 10 s around the Earth in the xz-plane (MyScene.ixx:240-248,270-277)
 //   * Earth / Star gravity on the other bodies is off by default (userData = false), their spin only matters with textures.
 struct MyScene : Scene {
-    explicit MyScene(unsigned seed = 0, bool textured = false) { Load(MySceneDesc(seed, textured)); m_initial = Desc.RenderObjects; }
+    explicit MyScene(unsigned seed = 0, bool textured = false, bool environmentMap = false)
+    {
+        Load(MySceneDesc(seed, textured, environmentMap));
+        m_initial = Desc.RenderObjects;
+    }
 
     bool IsStatic() const { return !m_isPhysXRunning; }
     void SetRunning(bool running) { m_isPhysXRunning = running; }

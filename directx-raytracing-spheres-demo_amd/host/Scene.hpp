@@ -34,6 +34,7 @@ struct SceneDesc {
     struct {
         Float4 Color{ 0, 0, 0, -1 };  // Scene.ixx:65: a < 0 -> procedural sky
         Quaternion Rotation;
+        std::string Texture;          // Scene.ixx:78: a lat-long environment map file, empty = none
     } EnvironmentLight;
 
     std::vector<RenderObjectDesc> RenderObjects;
@@ -65,6 +66,11 @@ struct Scene {
                 }
                 info.Descriptor = it->second;
             }
+        m_environmentDescriptor = ~0u;
+        if (!Desc.EnvironmentLight.Texture.empty()) {  // Scene.ixx:130-133
+            m_textures.emplace_back(m_loader ? m_loader(Desc.EnvironmentLight.Texture, EnvironmentLightTexture) : DefaultTextureLoader(Desc.EnvironmentLight.Texture, EnvironmentLightTexture));
+            m_environmentDescriptor = static_cast<uint32_t>(m_textures.size() - 1);
+        }
         Refresh();
     }
 
@@ -93,17 +99,23 @@ struct Scene {
     const std::vector<PtObjectTextures>& GetObjectTextures() const noexcept { return m_objectTextures; }
     const std::vector<float>& GetRotations() const noexcept { return m_rotations; }  // n x (x, y, z, w), world space
 
-    // SceneData as uploaded by App::UpdateScene (Source/App.cpp:977-990) with no environment texture.
+    // SceneData as uploaded by App::UpdateScene (Source/App.cpp:977-990).  EnvironmentLightTransform =
+    // XMStoreFloat3x4(Matrix::CreateFromQuaternion(Rotation)): the 3x4 store transposes DirectXMath's row-vector matrix, so
+    // the shader's mul((float3x3)M, v) rotates v by the quaternion.
     PtSceneData GetSceneData() const
     {
         PtSceneData sd{};
         sd.IsStatic = 1;
-        sd.EnvironmentLightTextureDescriptor = ~0u;
+        sd.EnvironmentLightTextureDescriptor = m_environmentDescriptor;
         sd.EnvironmentLightColor[0] = Desc.EnvironmentLight.Color.x;
         sd.EnvironmentLightColor[1] = Desc.EnvironmentLight.Color.y;
         sd.EnvironmentLightColor[2] = Desc.EnvironmentLight.Color.z;
         sd.EnvironmentLightColor[3] = Desc.EnvironmentLight.Color.w;
-        sd.EnvironmentLightTransform[0] = sd.EnvironmentLightTransform[5] = sd.EnvironmentLightTransform[10] = 1;
+        const auto& q = Desc.EnvironmentLight.Rotation;
+        float* m = sd.EnvironmentLightTransform;
+        m[0] = 1 - 2 * (q.y * q.y + q.z * q.z); m[1] = 2 * (q.x * q.y - q.z * q.w); m[2] = 2 * (q.x * q.z + q.y * q.w);
+        m[4] = 2 * (q.x * q.y + q.z * q.w); m[5] = 1 - 2 * (q.x * q.x + q.z * q.z); m[6] = 2 * (q.y * q.z - q.x * q.w);
+        m[8] = 2 * (q.x * q.z - q.y * q.w); m[9] = 2 * (q.y * q.z + q.x * q.w); m[10] = 1 - 2 * (q.x * q.x + q.y * q.y);
         return sd;
     }
 
@@ -113,6 +125,7 @@ private:
     std::vector<float> m_rotations;
     std::vector<Texture> m_textures;
     std::vector<PtObjectTextures> m_objectTextures;
+    uint32_t m_environmentDescriptor = ~0u;
     TextureLoader m_loader;
 };
 

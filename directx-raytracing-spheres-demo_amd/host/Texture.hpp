@@ -23,16 +23,23 @@ struct Texture {
     uint32_t Width = 0, Height = 0;
     bool ForceSRGB = false;           // colour data: sampled as DXGI_FORMAT_R8G8B8A8_UNORM_SRGB
     std::vector<uint8_t> Pixels;      // Width * Height * 4, row-major RGBA
+    std::vector<float> HDRPixels;     // or: Width * Height * 4 linear floats (an .exr / .hdr environment map); Pixels empty
+
+    bool IsHDR() const noexcept { return !HDRPixels.empty(); }
+    uint32_t Format() const noexcept { return IsHDR() ? PT_TEXTURE_RGBA32_FLOAT : ForceSRGB ? PT_TEXTURE_RGBA8_UNORM_SRGB : PT_TEXTURE_RGBA8_UNORM; }
+    size_t ByteSize() const noexcept { return IsHDR() ? HDRPixels.size() * sizeof(float) : Pixels.size(); }
+    const void* Data() const noexcept { return IsHDR() ? static_cast<const void*>(HDRPixels.data()) : Pixels.data(); }
 
     PtTexture ToPt() const
     {
         PtTexture t{};
-        t.Pixels = Pixels.data(); t.Width = Width; t.Height = Height;
-        t.Format = ForceSRGB ? PT_TEXTURE_RGBA8_UNORM_SRGB : PT_TEXTURE_RGBA8_UNORM;
+        t.Pixels = Data(); t.Width = Width; t.Height = Height; t.Format = Format();
         return t;
     }
 };
 
+// textureMapType: a TextureMapType, or EnvironmentLightTexture for SceneDesc::EnvironmentLight.Texture (Scene.ixx:130-133)
+constexpr uint32_t EnvironmentLightTexture = TextureMapType::Count;
 using TextureLoader = std::function<Texture(const std::string& path, uint32_t textureMapType)>;
 
 namespace procedural {
@@ -113,6 +120,35 @@ inline Texture NormalMap(uint32_t w, uint32_t h, unsigned seed, float strength)
     return t;
 }
 
+// HDR lat-long sky (u = (1 + atan2(x, z) / pi) / 2, v = acos(y) / pi: Math::ToLatLongCoordinate): zenith gradient, clouds above
+// the horizon, a ground tint and a small bright sun
+inline Texture Sky(uint32_t w, uint32_t h, unsigned seed)
+{
+    const auto clouds = ValueNoise(w, h, seed, 4), dirt = ValueNoise(w, h, seed + 1, 3);
+    Texture t; t.Width = w; t.Height = h; t.HDRPixels.resize(static_cast<size_t>(w) * h * 4);
+    const float pi = 3.14159265358979323846f;
+    const float sl = std::sqrt(0.4f * 0.4f + 0.6f * 0.6f + 0.7f * 0.7f), sun[3] = { 0.4f / sl, 0.6f / sl, 0.7f / sl };
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            const float theta = (y + 0.5f) / h * pi, phi = (2 * (x + 0.5f) / w - 1) * pi;
+            const float d[3] = { std::sin(theta) * std::sin(phi), std::cos(theta), std::sin(theta) * std::cos(phi) };
+            const size_t i = static_cast<size_t>(y) * w + x;
+            float c[3];
+            if (d[1] >= 0) {
+                const float up = std::fmin(d[1], 1.0f), cloud = std::fmax(clouds[i] - 0.5f, 0.0f) * 2 * std::fmin(d[1] * 3, 1.0f);
+                c[0] = (1 - up) * 0.9f + up * 0.15f + cloud; c[1] = (1 - up) * 0.9f + up * 0.35f + cloud; c[2] = (1 - up) * 0.95f + up * 0.9f + cloud;
+            } else {
+                const float k = 1 + 0.3f * dirt[i];
+                c[0] = 0.25f * k; c[1] = 0.22f * k; c[2] = 0.2f * k;
+            }
+            float s = (d[0] * sun[0] + d[1] * sun[1] + d[2] * sun[2] - 0.995f) / 0.005f;
+            s = std::fmin(std::fmax(s, 0.0f), 1.0f);
+            for (int k = 0; k < 3; k++) t.HDRPixels[4 * i + k] = c[k] + 40.0f * s * s;
+            t.HDRPixels[4 * i + 3] = 1;
+        }
+    return t;
+}
+
 }  // namespace procedural
 
 // Default loader: stand-ins keyed by the reference's file names (any other name gets a neutral grey / flat normal map).
@@ -122,6 +158,7 @@ inline Texture DefaultTextureLoader(const std::string& path, uint32_t type)
     constexpr float sea[3] = { 0.05f, 0.15f, 0.45f }, land[3] = { 0.25f, 0.45f, 0.15f };
     constexpr float mare[3] = { 0.25f, 0.25f, 0.27f }, highland[3] = { 0.65f, 0.63f, 0.6f };
     constexpr float dark[3] = { 0.25f, 0.3f, 0.28f }, bright[3] = { 0.75f, 0.8f, 0.7f };
+    if (type == EnvironmentLightTexture) return procedural::Sky(1024, 512, 21);  // stands in for 141_hdrmaps_com_free.exr (MyScene.ixx:95)
     if (type == TextureMapType::Normal)
         return procedural::NormalMap(has("Earth") ? 1024u : 512u, has("Earth") ? 512u : 256u, has("Earth") ? 11u : has("Moon") ? 12u : 13u, has("Moon") ? 8.0f : 4.0f);
     if (has("Earth")) return procedural::Albedo(1024, 512, 1, sea, land, 0.52f);

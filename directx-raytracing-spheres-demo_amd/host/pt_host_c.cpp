@@ -45,14 +45,17 @@ int pth_scene(uint32_t kind, uint32_t seed, uint32_t count_param, PtSphere* sphe
 // The demo scene with its textured objects (MySceneDesc(seed, true)) at simulation time `time`: texture table, per-object
 // maps and world-space rotations.  Two-step protocol: call with null arrays for the counts, then with storage.
 //   image_info[4 * t] = { width, height, format (PtTexture::Format), byte offset into `pixels` }
-int pth_demo_textures(uint32_t seed, double time, uint32_t* n_textures, uint32_t* n_objects, uint64_t* pixel_bytes,
-                      uint32_t* image_info, uint8_t* pixels, PtObjectTextures* object_textures, float* rotations)
+// flags: bit 0 = the textured objects, bit 1 = the lat-long environment map (MySceneDesc's `environmentMap`); scene_data (may
+// be null) receives the scene's SceneData (EnvironmentLightTextureDescriptor / Transform for bit 1).
+int pth_demo_textures_ex(uint32_t seed, double time, uint32_t flags, uint32_t* n_textures, uint32_t* n_objects, uint64_t* pixel_bytes,
+                         uint32_t* image_info, uint8_t* pixels, PtObjectTextures* object_textures, float* rotations, PtSceneData* scene_data)
 {
-    MyScene scene(seed, true);
+    MyScene scene(seed, (flags & 1u) != 0, (flags & 2u) != 0);
     scene.SetTime(time);
+    if (scene_data) *scene_data = scene.GetSceneData();
     const auto& tex = scene.GetTextures();
     uint64_t bytes = 0;
-    for (const auto& t : tex) bytes += t.Pixels.size();
+    for (const auto& t : tex) bytes += (t.ByteSize() + 15u) & ~size_t(15);
     if (n_textures) *n_textures = static_cast<uint32_t>(tex.size());
     if (n_objects) *n_objects = scene.GetObjectCount();
     if (pixel_bytes) *pixel_bytes = bytes;
@@ -60,14 +63,20 @@ int pth_demo_textures(uint32_t seed, double time, uint32_t* n_textures, uint32_t
     uint64_t off = 0;
     for (size_t t = 0; t < tex.size(); t++) {
         image_info[4 * t] = tex[t].Width; image_info[4 * t + 1] = tex[t].Height;
-        image_info[4 * t + 2] = tex[t].ForceSRGB ? PT_TEXTURE_RGBA8_UNORM_SRGB : PT_TEXTURE_RGBA8_UNORM;
+        image_info[4 * t + 2] = tex[t].Format();
         image_info[4 * t + 3] = static_cast<uint32_t>(off);
-        std::memcpy(pixels + off, tex[t].Pixels.data(), tex[t].Pixels.size());
-        off += tex[t].Pixels.size();
+        std::memcpy(pixels + off, tex[t].Data(), tex[t].ByteSize());
+        off += (tex[t].ByteSize() + 15u) & ~size_t(15);
     }
     std::memcpy(object_textures, scene.GetObjectTextures().data(), scene.GetObjectCount() * sizeof(PtObjectTextures));
     std::memcpy(rotations, scene.GetRotations().data(), scene.GetRotations().size() * sizeof(float));
     return 0;
+}
+
+int pth_demo_textures(uint32_t seed, double time, uint32_t* n_textures, uint32_t* n_objects, uint64_t* pixel_bytes,
+                      uint32_t* image_info, uint8_t* pixels, PtObjectTextures* object_textures, float* rotations)
+{
+    return pth_demo_textures_ex(seed, time, 1u, n_textures, n_objects, pixel_bytes, image_info, pixels, object_textures, rotations, nullptr);
 }
 
 // CameraController at `position` with identity rotation (or looking at `look_at` when non-null), SetLens(hfov, w/h),

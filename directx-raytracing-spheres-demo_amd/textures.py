@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-from .abi_types import (TEXTURE_MAP_COUNT, TEXTURE_RGBA8_UNORM, TEXTURE_RGBA8_UNORM_SRGB, PtObjectTextures, PtTexture)
+from .abi_types import (TEXTURE_MAP_COUNT, TEXTURE_RGBA8_UNORM, TEXTURE_RGBA8_UNORM_SRGB, TEXTURE_RGBA32_FLOAT, PtObjectTextures, PtTexture)
 
 NO_TEXTURE = 0xFFFFFFFF
 
@@ -28,6 +28,15 @@ class TextureSet:
         if a.shape[-1] == 3:
             a = np.concatenate([a, np.full(a.shape[:2] + (1,), 255, np.uint8)], -1)
         self.images.append((np.ascontiguousarray(a), TEXTURE_RGBA8_UNORM_SRGB if srgb else TEXTURE_RGBA8_UNORM))
+        return len(self.images) - 1
+
+    def add_hdr_image(self, rgba):
+        """rgba: float32 (h, w, 4) or (h, w, 3) linear HDR texels (PT_TEXTURE_RGBA32_FLOAT), e.g. a lat-long environment map
+        that SceneData.EnvironmentLightTextureDescriptor then names by the returned index"""
+        a = np.asarray(rgba, dtype=np.float32)
+        if a.shape[-1] == 3:
+            a = np.concatenate([a, np.ones(a.shape[:2] + (1,), np.float32)], -1)
+        self.images.append((np.ascontiguousarray(a), TEXTURE_RGBA32_FLOAT))
         return len(self.images) - 1
 
     def assign(self, sphere, map_type, texture_index):
@@ -103,6 +112,23 @@ def normal_map_from_height(height, strength=4.0):
     nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
     enc = np.clip(np.rint((nrm + 1.0) * 127.0), 0, 254)
     return np.concatenate([enc[..., :2], np.full(hgt.shape + (1,), 255.0)], -1).astype(np.uint8)
+
+
+def sky_latlong(w, h, seed=0, sun_dir=(0.4, 0.6, 0.7), sun_radiance=40.0):
+    """a procedural HDR lat-long environment map, float32 (h, w, 3): horizon-to-zenith gradient, tileable clouds, a ground
+    tint and a small bright sun -- the stand-in for the reference's Assets/Textures/*.exr|hdr environment (not shippable).
+    Texel (x, y) covers u = (x + .5) / w, v = (y + .5) / h of Math::ToLatLongCoordinate."""
+    v, u = np.meshgrid((np.arange(h) + 0.5) / h, (np.arange(w) + 0.5) / w, indexing="ij")
+    theta, phi = v * np.pi, (2 * u - 1) * np.pi          # v = acos(y) / pi, u = (1 + atan2(x, z) / pi) / 2
+    d = np.stack([np.sin(theta) * np.sin(phi), np.cos(theta), np.sin(theta) * np.cos(phi)], -1)
+    t = np.clip(d[..., 1], 0, 1)[..., None]
+    sky = (1 - t) * np.array([0.9, 0.9, 0.95]) + t * np.array([0.15, 0.35, 0.9])
+    clouds = np.clip(value_noise(w, h, seed, octaves=4) - 0.5, 0, 1)[..., None] * 2.0 * np.clip(d[..., 1:2] * 3, 0, 1)
+    ground = np.array([0.25, 0.22, 0.2]) * (1 + 0.3 * value_noise(w, h, seed + 1, octaves=3)[..., None])
+    img = np.where(d[..., 1:2] >= 0, sky + clouds, ground)
+    s = np.asarray(sun_dir, np.float64); s = s / np.linalg.norm(s)
+    img = img + sun_radiance * np.clip((d @ s - 0.995) / 0.005, 0, 1)[..., None] ** 2
+    return img.astype(np.float32)
 
 
 def load_image(path, srgb_hint=None):

@@ -168,9 +168,13 @@ PtStatus pt_unpack_tiles_rgb(PtContext *ctx, const void *packed_device, uint64_t
  * 161-235) over analytic sphere UVs / tangents (csrc/pt_texture.h).  Replaces the texture part of Scene::Load
  * (Source/Scene.ixx:123-180: per-object Textures -> TextureMapInfoArray in ObjectData).  Call after pt_set_scene:
  *   textures[n_textures]   decoded images (copied; converted to linear float4 on upload)
- *   object_textures[n]     one TextureMapInfoArray per sphere (n = the scene's sphere count); Descriptor < n_textures or ~0u
+ *   object_textures[n]     one TextureMapInfoArray per sphere (n = the scene's sphere count); Descriptor < n_textures or ~0u;
+ *                          NULL = no sphere has maps (the table then only holds the environment map)
  *   rotations              n unit quaternions (x, y, z, w): object -> world rotation of each sphere, NULL = identity
  * n_textures == 0 removes all textures.  Every kernel that shades has a textured variant, selected per launch.
+ * The table is also where SceneData.EnvironmentLightTextureDescriptor points (row a18's texture branch,
+ * ShadingHelpers.hlsli:13-24: a lat-long map, usually PT_TEXTURE_RGBA32_FLOAT); pt_render* fails with PT_ERR_STATE while the
+ * scene names an environment texture the table does not hold.
  * pt_update_rotations replaces the quaternions (Earth's spin, the Moon's tidal lock: Source/MyScene.ixx:240-291); it
  * waits for the frames in flight. */
 PtStatus pt_set_textures(PtContext *ctx, const PtTexture *textures, uint32_t n_textures,

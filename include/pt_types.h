@@ -71,8 +71,11 @@ typedef struct PtCamera {
 } PtCamera;
 
 /* Source/CommonShaderData.ixx:15-20. EnvironmentLightColor.a < 0 selects the
- * procedural sky (Shaders/ShadingHelpers.hlsli:25-29); the descriptor must be
- * ~0u (environment textures are a "next" row). */
+ * procedural sky (Shaders/ShadingHelpers.hlsli:25-29).  EnvironmentLightTextureDescriptor
+ * != ~0u selects a lat-long environment map (ShadingHelpers.hlsli:13-24): it indexes the
+ * PtTexture table given to pt_set_textures (this path's descriptor heap), the lookup
+ * direction is rotated by the upper 3x3 of EnvironmentLightTransform.  Cube maps
+ * (IsEnvironmentLightTextureCubeMap) are not supported. */
 typedef struct PtSceneData {
     uint32_t IsStatic;                          /*  0 */
     uint32_t IsEnvironmentLightTextureCubeMap;  /*  4 */
@@ -121,13 +124,14 @@ typedef struct PtObjectTextures {
 /* A decoded image as the reference's TextureHelpers hands it to D3D12 (Source/TextureHelpers.ixx:34-60): 8-bit RGBA texels,
  * either linear (DXGI_FORMAT_R8G8B8A8_UNORM) or sRGB-encoded colour (.._UNORM_SRGB, `forceSRGB`); alpha is always linear. */
 typedef struct PtTexture {
-    const void *Pixels;    /* host pointer, Width * Height * 4 bytes, row-major, tightly packed */
+    const void *Pixels;    /* host pointer, Width * Height texels of 4 bytes (RGBA8) or 16 bytes (RGBA32_FLOAT), row-major, tightly packed */
     uint32_t Width, Height;
-    uint32_t Format;       /* PT_TEXTURE_RGBA8_UNORM | PT_TEXTURE_RGBA8_UNORM_SRGB */
+    uint32_t Format;       /* PT_TEXTURE_RGBA8_UNORM | PT_TEXTURE_RGBA8_UNORM_SRGB | PT_TEXTURE_RGBA32_FLOAT */
     uint32_t _pad;
 } PtTexture;
 
-enum { PT_TEXTURE_RGBA8_UNORM = 0, PT_TEXTURE_RGBA8_UNORM_SRGB = 1 };
+/* RGBA32_FLOAT: linear HDR texels, what the reference's EXR/HDR environment maps decode to (DXGI_FORMAT_R32G32B32A32_FLOAT) */
+enum { PT_TEXTURE_RGBA8_UNORM = 0, PT_TEXTURE_RGBA8_UNORM_SRGB = 1, PT_TEXTURE_RGBA32_FLOAT = 2 };
 
 /* Display transform parameters (row N3): what App::Impl::ToneMap hands to DirectXTK's ToneMapPostProcess
  * (Source/App.cpp:1731-1757; operator / transfer-function pairs created at Source/App.cpp:760-769). */

@@ -63,6 +63,7 @@ def declare_leaf_api(lib, prefix):
     fn("sample_sphere_cone", C.c_int, [pf, pf, f, f, f, pf, pf])
     fn("atan2", f, [f, f])
     fn("sphere_uv", None, [pf, pf])
+    fn("latlong_uv", None, [pf, pf])
     fn("sphere_tangent", None, [pf, pf])
     fn("quat_rotate", None, [pf, pf, pf])
     fn("perturb_normal", None, [pf, pf, f, f, pf])

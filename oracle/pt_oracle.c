@@ -307,8 +307,11 @@ void oracle_environment_term_rtg(const float f0[3], float nov, float roughness, 
 }
 
 /* ------------------------------------------------------------------ environment (ShadingHelpers.hlsli:11-30) */
-static v3 environment_color(const PtSceneData *sd, v3 d)
+struct tex_ctx_s;
+static v3 environment_texture(const struct tex_ctx_s *tc, const PtSceneData *sd, v3 d);
+static v3 environment_color(const struct tex_ctx_s *tc, const PtSceneData *sd, v3 d)
 {
+    if (sd->EnvironmentLightTextureDescriptor != 0xFFFFFFFFu && tc) return environment_texture(tc, sd, d); /* :13-24; oracle_render_textured has checked the descriptor */
     if (sd->EnvironmentLightColor[3] >= 0.0f)
         return V3(sd->EnvironmentLightColor[0], sd->EnvironmentLightColor[1], sd->EnvironmentLightColor[2]);
     /* Procedural sky: FromSrgb(lerp(1, (0.5, 0.7, 1), (d.y + 1) / 2)) per channel (ShadingHelpers.hlsli:29).  Each channel
@@ -322,7 +325,7 @@ static v3 environment_color(const PtSceneData *sd, v3 d)
 }
 void oracle_sky(const PtSceneData *scene, const float dir[3], float out[3])
 {
-    v3 c = environment_color(scene, V3(dir[0], dir[1], dir[2])); out[0] = c.x; out[1] = c.y; out[2] = c.z;
+    v3 c = environment_color(NULL, scene, V3(dir[0], dir[1], dir[2])); out[0] = c.x; out[1] = c.y; out[2] = c.z;
 }
 
 /* ------------------------------------------------------------------ ray-sphere (build-defined, replaces CastRay) */
@@ -804,7 +807,7 @@ static void trace_event(trace_t *tr, uint32_t s, uint32_t bnc, const hit_t *h, i
  * specs S6-S8): GeoSphere texture coordinates from the object-space normal, tangent along increasing u, level-0 bilinear
  * wrap sampling, and a fixed-polynomial atan2.
  * ---------------------------------------------------------------------------------------------------------------- */
-typedef struct {
+typedef struct tex_ctx_s {
     const OracleTextures *t;
     float unorm[256], srgb[256]; /* 8-bit code -> linear value */
 } tex_ctx;
@@ -875,6 +878,11 @@ static float lerp1(float a, float b, float t) { return FMA(t, b - a, a); }
 
 static void fetch_texel(const tex_ctx *c, const PtTexture *tx, uint32_t x, uint32_t y, float out[4])
 {
+    if (tx->Format == PT_TEXTURE_RGBA32_FLOAT) { /* linear HDR texels (environment maps) */
+        const float *f = (const float *)tx->Pixels + 4u * ((size_t)y * tx->Width + x);
+        out[0] = f[0]; out[1] = f[1]; out[2] = f[2]; out[3] = f[3];
+        return;
+    }
     const uint8_t *p = (const uint8_t *)tx->Pixels + 4u * ((size_t)y * tx->Width + x);
     const float *lut = tx->Format == PT_TEXTURE_RGBA8_UNORM_SRGB ? c->srgb : c->unorm;
     out[0] = lut[p[0]]; out[1] = lut[p[1]]; out[2] = lut[p[2]]; out[3] = c->unorm[p[3]];
@@ -903,6 +911,25 @@ void oracle_sample_texture(const OracleTextures *t, uint32_t index, const float 
     tex_ctx c;
     tex_ctx_init(&c, t);
     sample_bilinear(&c, index, uv, out);
+}
+
+/* GetEnvironmentLightColor's texture branch (ShadingHelpers.hlsli:13-24) for a lat-long map: the direction is rotated by the
+ * upper 3x3 of EnvironmentLightTransform (Geometry::RotateVector = mul(M, v): component i = dot(row i, v)), normalised, mapped
+ * by Math::ToLatLongCoordinate (Math.hlsli:29-33: u = (1 + atan2(x, z) / pi) / 2, v = acos(y) / pi) and sampled at level 0. */
+void oracle_latlong_uv(const float d[3], float uv[2])
+{
+    uv[0] = FMA(oracle_atan2(d[0], d[2]), 0.15915494309189533577f, 0.5f);
+    uv[1] = oracle_atan2(sqrtf(f_max(FMA(-d[1], d[1], 1.0f), 0.0f)), d[1]) * 0.31830988618379067154f;
+}
+
+static v3 environment_texture(const tex_ctx *tc, const PtSceneData *sd, v3 d)
+{
+    const float *m = sd->EnvironmentLightTransform;
+    v3 r = v_normalize(V3(v_dot(V3(m[0], m[1], m[2]), d), v_dot(V3(m[4], m[5], m[6]), d), v_dot(V3(m[8], m[9], m[10]), d)));
+    float dir[3] = { r.x, r.y, r.z }, uv[2], s[4];
+    oracle_latlong_uv(dir, uv);
+    sample_bilinear(tc, sd->EnvironmentLightTextureDescriptor, uv, s);
+    return V3(s[0], s[1], s[2]);
 }
 
 /* PerturbNormal: Geometry::UnpackLocalNormal (MathLib, recollection) + CalculateTBN + RotateVectorInverse */
@@ -938,7 +965,7 @@ static material_eval evaluate_material(const tex_ctx *tc, const PtMaterial *m, c
     e.emissive_strength = m->EmissiveStrength;
     e.metallic = m->Metallic; e.roughness = m->Roughness; e.ior = m->IOR; e.transmission = m->Transmission;
     e.shadingN = h->shadingN;
-    if (!tc) return e;
+    if (!tc || !tc->t->object_textures) return e;
     const PtTextureMapInfo *maps = tc->t->object_textures[h->id].Maps;
     int any = 0;
     for (int k = 0; k < PT_TEXTURE_MAP_COUNT; k++) any |= maps[k].Descriptor != ~0u;
@@ -1040,7 +1067,7 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
     const int di_on = gs->IsDIEnabled && lights && lights->n > 0;
     if (di_on) rays++; /* the DI pass traces the primary ray again */
     if (!primary.hit) { /* miss: Radiance = env (GBufferGeneration.hlsl:223-227); bounce loop returns without writing (:249-252) */
-        v3 c = environment_color(sd, d);
+        v3 c = environment_color(tc, sd, d);
         rgba[0] = c.x; rgba[1] = c.y; rgba[2] = c.z; rgba[3] = 1.0f;
         trace_event(tr, 0, 0, &primary, 0, V3(0, 0, 0), V3(1, 1, 1), rng, -1, 1);
         return rays;
@@ -1109,7 +1136,7 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
                 rays++;
             }
             if (!is_hit) { /* :242-259 (bnc > 0 here) */
-                v3 env = environment_color(sd, rd);
+                v3 env = environment_color(tc, sd, rd);
                 sample_radiance = v_add(sample_radiance, v_mul(T, env));
                 trace_event(tr, s, bnc, &hit, 0, L, T, rng, lobe, 2);
                 break;
@@ -1260,16 +1287,17 @@ static int validate(const PtSceneData *sd, const PtGraphicsSettings *gs, uint32_
     if (gs->RenderSize[0] == 0 || gs->RenderSize[1] == 0 || gs->SamplesPerPixel == 0) return 2;
     if (gs->RenderSize[0] > 65535u || gs->RenderSize[1] > 65535u) return 2; /* (px<<16)|py seed */
     if (gs->Denoiser) return 3;
-    if (sd->EnvironmentLightTextureDescriptor != 0xFFFFFFFFu) return 4;
+    if (sd->EnvironmentLightTextureDescriptor != 0xFFFFFFFFu && sd->IsEnvironmentLightTextureCubeMap) return 4; /* lat-long maps only */
     return 0;
 }
 
 static int validate_textures(const OracleTextures *t, uint32_t n)
 {
     if (!t || t->n_textures == 0) return 0;
-    if (!t->textures || !t->object_textures) return 6;
+    if (!t->textures) return 6;
     for (uint32_t i = 0; i < t->n_textures; i++)
-        if (!t->textures[i].Pixels || !t->textures[i].Width || !t->textures[i].Height || t->textures[i].Format > PT_TEXTURE_RGBA8_UNORM_SRGB) return 6;
+        if (!t->textures[i].Pixels || !t->textures[i].Width || !t->textures[i].Height || t->textures[i].Format > PT_TEXTURE_RGBA32_FLOAT) return 6;
+    if (!t->object_textures) return 0; /* an environment map alone */
     for (uint32_t i = 0; i < n; i++)
         for (int k = 0; k < PT_TEXTURE_MAP_COUNT; k++) {
             const PtTextureMapInfo *mi = &t->object_textures[i].Maps[k];
@@ -1294,6 +1322,8 @@ int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials,
     int err = validate(scene, gs, n);
     if (err) return err;
     if ((err = validate_textures(textures, n)) != 0) return err;
+    if (scene->EnvironmentLightTextureDescriptor != 0xFFFFFFFFu && (!textures || scene->EnvironmentLightTextureDescriptor >= textures->n_textures))
+        return 4; /* the descriptor indexes the texture table */
     tex_ctx tc;
     const int textured = textures && textures->n_textures > 0;
     if (textured) tex_ctx_init(&tc, textures);

@@ -38,9 +38,9 @@ int oracle_render(const PtSphere *spheres, const PtMaterial *materials, uint32_t
 /* Row N1: the same render with textured spheres (EvaluateMaterial's texture branches, Shaders/ShadingHelpers.hlsli:53-103,
  * 161-235).  `textures` may be NULL (= oracle_render). */
 typedef struct OracleTextures {
-    const PtTexture *textures;               /* decoded 8-bit RGBA images */
+    const PtTexture *textures;               /* decoded images; SceneData.EnvironmentLightTextureDescriptor indexes this table too */
     uint32_t n_textures;
-    const PtObjectTextures *object_textures; /* one TextureMapInfoArray per sphere */
+    const PtObjectTextures *object_textures; /* one TextureMapInfoArray per sphere, or NULL = no sphere has maps */
     const float *rotations;                  /* n quaternions (x, y, z, w) object -> world, or NULL = identity */
 } OracleTextures;
 int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials, uint32_t n,
@@ -57,6 +57,7 @@ int oracle_sample_sphere_cone(const float P[3], const float C[3], float r, float
 /* leaves of row N1 */
 float oracle_atan2(float y, float x);
 void oracle_sphere_uv(const float n[3], float uv[2]);
+void oracle_latlong_uv(const float d[3], float uv[2]); /* Math::ToLatLongCoordinate (Math.hlsli:29-33), row a18's texture branch */
 void oracle_sphere_tangent(const float n[3], float t[3]);
 void oracle_quat_rotate(const float q[4], const float v[3], float out[3]);
 void oracle_sample_texture(const OracleTextures *t, uint32_t index, const float uv[2], float out[4]);

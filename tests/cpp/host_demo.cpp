@@ -1,7 +1,8 @@
 // host_demo.cpp -- drives the C-ABI through the C++ host mirror exactly as INTEGRATION.md describes (the reference's
 // own host is C++): MySceneDesc -> Scene::Load -> Raytracing::SetScene / SetCamera / SetConstants / Render.
-// Usage: host_demo <small|demo|textured> <width> <height> <bounces> <spp> <frame> <out.f32>
+// Usage: host_demo <small|demo|textured|environment> <width> <height> <bounces> <spp> <frame> <out.f32>
 //   textured = the demo scene with its textured objects (MySceneDesc(seed, true)) after 3 s of motion (MyScene::SetTime)
+//   environment = textured + the lat-long environment light (MySceneDesc(seed, true, true))
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,14 +13,15 @@
 
 int main(int argc, char** argv)
 {
-    if (argc != 8) { std::fprintf(stderr, "usage: %s <small|demo|textured> w h bounces spp frame out.f32\n", argv[0]); return 2; }
+    if (argc != 8) { std::fprintf(stderr, "usage: %s <small|demo|textured|environment> w h bounces spp frame out.f32\n", argv[0]); return 2; }
     try {
         const bool small = std::strcmp(argv[1], "small") == 0;
         const uint32_t w = std::atoi(argv[2]), h = std::atoi(argv[3]), bounces = std::atoi(argv[4]), spp = std::atoi(argv[5]), frame = std::atoi(argv[6]);
         dxrs::DeviceContext device;  // throws without a GPU: there is no fallback
         dxrs::Raytracing raytracing(device);
-        const bool textured = std::strcmp(argv[1], "textured") == 0;
-        dxrs::MyScene moving(0, textured);
+        const bool environment = std::strcmp(argv[1], "environment") == 0;
+        const bool textured = environment || std::strcmp(argv[1], "textured") == 0;
+        dxrs::MyScene moving(0, textured, environment);
         if (textured) moving.SetTime(3.0);  // the Earth has turned, the Moon has moved and turned with it
         dxrs::Scene still;
         if (small) still.Load(dxrs::SmallSceneDesc(0)); else still.Load(dxrs::MySceneDesc(0));

@@ -60,3 +60,33 @@ def test_cpp_host_textured_demo_matches_python_path_and_oracle(dxrs, host, oracl
     assert ost.rays == st.rays and np.array_equal(ref.view(np.uint32)[..., :3], img_py.view(np.uint32)[..., :3])
     plain, _ = oracle.render(spheres, materials, sd, cam, gs, threads=8)
     assert not np.array_equal(plain.view(np.uint32), ref.view(np.uint32))
+
+
+def test_cpp_host_environment_map_matches_python_path_and_oracle(dxrs, host, oracle, renderer, demo_exe, tmp_path):
+    """row a18's texture branch through the C++ mirror: SceneDesc::EnvironmentLight.{Texture, Rotation} -> Scene::Load ->
+    SceneData.EnvironmentLightTextureDescriptor / Transform (MyScene.ixx:94-95, App.cpp:982-986)"""
+    w, h, bounces, spp, frame = 320, 180, 4, 1, 1
+    out = str(tmp_path / "frame_env.f32")
+    res = subprocess.run([demo_exe, "environment", str(w), str(h), str(bounces), str(spp), str(frame), out], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    img_cpp = np.fromfile(out, dtype=np.float32).reshape(h, w, 4)
+    _, materials, _ = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    spheres = host.scene_at_time(0, 3.0)
+    ts, sd = host.demo_textures(0, 3.0, environment_map=True, return_scene_data=True)
+    assert sd.EnvironmentLightTextureDescriptor == len(ts.images) - 1
+    m = np.array(sd.EnvironmentLightTransform[:]).reshape(3, 4)[:, :3]
+    assert np.allclose(m, np.diag([-1, 1, -1]), atol=1e-6)  # yaw pi
+    cam = host.camera(w, h, jitter_index=frame)
+    gs = dxrs.types.graphics_settings(w, h, frame_index=frame, bounces=bounces, spp=spp)
+    renderer.set_scene(spheres, materials, sd)
+    renderer.set_textures(ts)
+    renderer.set_camera(cam); renderer.set_constants(gs)
+    img_py, st = renderer.render()
+    renderer.set_textures(None)
+    assert f"rays {st.rays} " in res.stdout
+    assert np.array_equal(img_cpp.view(np.uint32), img_py.view(np.uint32))
+    ref, ost = oracle.render(spheres, materials, sd, cam, gs, threads=8, textures=ts)
+    assert ost.rays == st.rays and np.array_equal(ref.view(np.uint32)[..., :3], img_py.view(np.uint32)[..., :3])
+    sky_only = host.scene(dxrs.host.SCENE_DEMO, seed=0)[2]
+    plain, _ = oracle.render(spheres, materials, sky_only, cam, gs, threads=8, textures=host.demo_textures(0, 3.0))
+    assert not np.array_equal(plain.view(np.uint32), ref.view(np.uint32))

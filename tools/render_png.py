@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--time", type=float, default=0.0, help="simulation time of the closed-form motion")
     ap.add_argument("--textures", action="store_true", help="textured Alien-Metal / Moon / Earth (procedural stand-ins)")
+    ap.add_argument("--env-map", action="store_true", help="lat-long HDR environment light (MyScene.ixx:94-95; procedural stand-in) instead of the sky")
     ap.add_argument("--texture-dir", default=None, help="directory with the reference's Assets/Textures files: use the real images")
     ap.add_argument("--operator", choices=["saturate", "reinhard", "aces"], default="aces")
     ap.add_argument("--exposure", type=float, default=0.0, help="stops")
@@ -41,10 +42,14 @@ def main():
     torch.cuda.init()
     stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
     r = dxrs_amd.Renderer(stream=stream.cuda_stream)
+    textured = bool(args.textures or args.texture_dir)
+    if textured or args.env_map:
+        ts, sd_env = host.demo_textures(0, args.time, textured=textured, environment_map=args.env_map, return_scene_data=True)
+        if args.env_map:
+            sd = sd_env
     r.set_scene(spheres, materials, sd)
-    if args.textures or args.texture_dir:
-        ts = host.demo_textures(0, args.time)
-        if args.texture_dir:  # replace the stand-ins by decoded files, same slots (order: MyScene.ixx:161-166, 285-295)
+    if textured or args.env_map:
+        if args.texture_dir and textured:  # replace the stand-ins by decoded files, same slots (order: MyScene.ixx:161-166, 285-295)
             from dxrs_amd.textures import load_image
             names = ["Alien-Metal_Albedo.png", "Alien-Metal_Metallic.png", "Alien-Metal_Roughness.png", "Alien-Metal_Normal.png",
                      "Moon_BaseColor.jpg", "Moon_Normal.jpg", "Earth_BaseColor.jpg", "Earth_Normal.jpg"]
