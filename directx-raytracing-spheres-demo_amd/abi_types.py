@@ -91,7 +91,7 @@ class PtConfig(C.Structure):
 class PtAccelInfo(C.Structure):
     _fields_ = [
         ("leaf_count", C.c_uint32), ("node_count", C.c_uint32), ("depth", C.c_uint32), ("lds_resident", C.c_uint32),
-        ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3), ("build_ms", C.c_float), ("_reserved", C.c_uint32),
+        ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3), ("build_ms", C.c_float), ("builder", C.c_uint32),
     ]
 
 
@@ -132,6 +132,8 @@ PT_FLAG_HOST_LBVH = 4
 PT_FLAG_SPLIT_KERNELS = 8
 PT_FLAG_TWO_FRAMES_IN_FLIGHT = 16
 PT_FLAG_DEFAULT_STREAM = 32
+PT_FLAG_FAST_BUILD = 64
+PT_BUILDER_DEVICE_LBVH, PT_BUILDER_HOST_LBVH, PT_BUILDER_HOST_SAH = 0, 1, 2
 
 
 def default_material(n=1):

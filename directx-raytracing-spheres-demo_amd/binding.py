@@ -17,7 +17,7 @@ STATUS = {0: "PT_OK", 1: "PT_ERR_INVALID_ARG", 2: "PT_ERR_NO_DEVICE", 3: "PT_ERR
 API_SYMBOLS = [
     "pt_create", "pt_destroy", "pt_set_scene", "pt_build_accel", "pt_update_spheres", "pt_refit_accel", "pt_set_camera", "pt_set_constants", "pt_render",
     "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_set_partition_ex", "pt_tiles_count_ex", "pt_unpack_tiles_ex", "pt_tonemap", "pt_accumulate", "pt_set_textures", "pt_update_rotations", "pt_pack_rgb", "pt_unpack_tiles_rgb", "pt_trace_rays", "pt_trace_rays_stats", "pt_accel_download",
-    "pt_accel_download_order", "pt_lbvh_build_host", "pt_set_profiling", "pt_get_profile", "pt_get_totals", "pt_get_queue_sizes", "pt_synchronize", "pt_last_error", "pt_version",
+    "pt_accel_download_order", "pt_lbvh_build_host", "pt_sah_build_host", "pt_set_profiling", "pt_get_profile", "pt_get_totals", "pt_get_queue_sizes", "pt_synchronize", "pt_last_error", "pt_version",
 ]
 
 
@@ -92,6 +92,8 @@ class HipLib:
         lib.pt_accel_download_order.argtypes = [vp, vp, u32]
         lib.pt_lbvh_build_host.restype = C.c_int
         lib.pt_lbvh_build_host.argtypes = [vp, u32, vp, vp, C.POINTER(u32)]
+        lib.pt_sah_build_host.restype = C.c_int
+        lib.pt_sah_build_host.argtypes = [vp, u32, vp, vp, C.POINTER(u32)]
         lib.pt_set_profiling.restype = C.c_int
         lib.pt_set_profiling.argtypes = [vp, C.c_int]
         lib.pt_get_profile.restype = C.c_int
@@ -108,14 +110,16 @@ class HipLib:
         lib.pt_version.argtypes = []
 
 
-    def lbvh_build_host(self, spheres):
-        """Host LBVH builder (no GPU needed) -> (nodes[BVH_NODE_DTYPE], sorted_id, depth)."""
+    def lbvh_build_host(self, spheres, sah=False):
+        """Host LBVH builder, or with sah=True the host SAH builder of small scenes (no GPU needed)
+        -> (nodes[BVH_NODE_DTYPE], sorted_id, depth)."""
         spheres = np.ascontiguousarray(spheres)
         n = len(spheres)
         nodes = np.zeros(max(n - 1, 0), dtype=BVH_NODE_DTYPE)
         order = np.zeros(n, dtype=np.uint32)
         depth = C.c_uint32(0)
-        st = self.lib.pt_lbvh_build_host(spheres.ctypes.data, n, nodes.ctypes.data if n > 1 else None, order.ctypes.data, C.byref(depth))
+        fn = self.lib.pt_sah_build_host if sah else self.lib.pt_lbvh_build_host
+        st = fn(spheres.ctypes.data, n, nodes.ctypes.data if n > 1 else None, order.ctypes.data, C.byref(depth))
         if st != 0:
             raise PtError(st, "pt_lbvh_build_host")
         return nodes, order, depth.value

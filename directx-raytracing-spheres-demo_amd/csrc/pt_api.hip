@@ -23,6 +23,7 @@ using namespace pt;
 namespace {
 
 constexpr uint32_t kMaxLdsBytes = 160u * 1024u;  // gfx950 LDS per CU / per workgroup
+constexpr uint32_t kSahMaxSpheres = 4096u;        // host SAH topology up to here, device LBVH above (pt_build_accel)
 constexpr uint32_t kLdsSceneBudget = 64u * 1024u; // stage the BVH in LDS only while two 512-thread blocks still fit per CU
 
 struct EventPair {
@@ -733,6 +734,7 @@ PtStatus pt_build_accel(PtContext* c, PtAccelInfo* info)
     }
     c->n_nodes = n > 1 ? n - 1 : 0;
     float build_ms = 0;
+    uint32_t builder_kind;
     if ((c->flags & PT_FLAG_HOST_LBVH) || !lbvh_gpu_available()) {
         auto t0 = std::chrono::steady_clock::now();
         build_lbvh_host(c->h_sph.data(), n, c->lbvh);
@@ -743,14 +745,31 @@ PtStatus pt_build_accel(PtContext* c, PtAccelInfo* info)
         PT_HIP(c, hipMemcpyAsync(c->d_sorted_id, c->lbvh.sorted_id.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         PT_HIP(c, hipStreamSynchronize(c->stream));
         c->depth = c->lbvh.depth;
+        builder_kind = PT_BUILDER_HOST_LBVH;
     } else {
         if (!c->gpu_builder) {
             c->gpu_builder = lbvh_gpu_create();
             if (!c->gpu_builder) return fail(c, PT_ERR_OOM, "pt_build_accel: cannot create the device LBVH builder");
         }
         LbvhGpuInfo gi{};
-        hipError_t e = lbvh_gpu_build(c->gpu_builder, c->d_sph, n, reinterpret_cast<PtBvhNode*>(c->d_nodes), c->d_sph_sorted, c->d_sorted_id, c->stream, &gi);
-        if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP, std::string("device LBVH build: ") + hipGetErrorString(e));
+        hipError_t e;
+        // Small scenes get a SAH topology from the host (the PREFER_FAST_TRACE analogue: 7 % fewer cycles per C2 frame than the
+        // Morton-order tree; the build is tens of microseconds at this size); larger ones the device LBVH, whose cost stays
+        // O(n) on the GPU.  PT_FLAG_FAST_BUILD / PT_SAH=0 keep the LBVH everywhere.
+        const bool sah = !(c->flags & PT_FLAG_FAST_BUILD) && n > 2 && n <= env_u32("PT_SAH_MAX_SPHERES", kSahMaxSpheres) && env_u32("PT_SAH", 1u) != 0;
+        if (sah) {
+            auto t0 = std::chrono::steady_clock::now();
+            build_sah_host(c->h_sph.data(), n, c->lbvh);
+            auto t1 = std::chrono::steady_clock::now();
+            e = lbvh_gpu_adopt(c->gpu_builder, c->d_sph, n, c->lbvh.nodes.data(), c->lbvh.sorted_id.data(), c->lbvh.depth,
+                               reinterpret_cast<PtBvhNode*>(c->d_nodes), c->d_sph_sorted, c->d_sorted_id, c->stream, &gi);
+            gi.build_ms += std::chrono::duration<float, std::milli>(t1 - t0).count();
+            builder_kind = PT_BUILDER_HOST_SAH;
+        } else {
+            e = lbvh_gpu_build(c->gpu_builder, c->d_sph, n, reinterpret_cast<PtBvhNode*>(c->d_nodes), c->d_sph_sorted, c->d_sorted_id, c->stream, &gi);
+            builder_kind = PT_BUILDER_DEVICE_LBVH;
+        }
+        if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP, std::string("device BVH build: ") + hipGetErrorString(e));
         c->depth = gi.depth;
         build_ms = gi.build_ms;
         c->lbvh = LbvhResult{};
@@ -771,6 +790,7 @@ PtStatus pt_build_accel(PtContext* c, PtAccelInfo* info)
         info->lds_resident = c->lds_scene ? 1u : 0u;
         for (int a = 0; a < 3; a++) { info->bounds_min[a] = c->lbvh.bounds_min[a]; info->bounds_max[a] = c->lbvh.bounds_max[a]; }
         info->build_ms = build_ms;
+        info->builder = builder_kind;
     }
     return PT_OK;
 }

@@ -28,5 +28,7 @@ uint32_t morton30(float x, float y, float z);
 float lbvh_padding(const float bmin[3], const float bmax[3]);
 
 void build_lbvh_host(const PtSphere* spheres, uint32_t n, LbvhResult& out);
+// SAH topology for small scenes (same record format; see pt_lbvh.cpp)
+void build_sah_host(const PtSphere* spheres, uint32_t n, LbvhResult& out);
 
 }  // namespace pt

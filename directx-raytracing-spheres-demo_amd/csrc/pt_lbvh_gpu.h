@@ -27,6 +27,10 @@ void lbvh_gpu_destroy(LbvhGpu* b);
 hipError_t lbvh_gpu_build(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode* d_nodes, float4* d_sorted, uint32_t* d_sorted_id,
                           hipStream_t stream, LbvhGpuInfo* info);
 
+// Adopt a topology built on the host (links + leaf order; the boxes are computed here by the refit passes).
+hipError_t lbvh_gpu_adopt(LbvhGpu* b, const float4* d_sph, uint32_t n, const PtBvhNode* h_nodes, const uint32_t* h_sorted_id, uint32_t depth,
+                          PtBvhNode* d_nodes, float4* d_sorted, uint32_t* d_sorted_id, hipStream_t stream, LbvhGpuInfo* info);
+
 // Refit after the spheres moved (same count, same topology as the last build): re-gather the Morton-ordered sphere
 // copy and recompute every box bottom-up.  Asynchronous on `stream`; flags (n words) and hdr (16 words) are scratch the
 // caller owns (one set per stream that may refit concurrently).

@@ -342,23 +342,41 @@ void lbvh_gpu_destroy(LbvhGpu* b)
 
 #define LB_CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 
+static hipError_t ensure_capacity(LbvhGpu* b, uint32_t n, hipStream_t stream)
+{
+    if (n <= b->cap) return hipSuccess;
+    LB_CK(hipStreamSynchronize(stream));
+    free_buffers(b);
+    LB_CK(hipMalloc(&b->keys_in, (size_t)n * sizeof(unsigned long long)));
+    LB_CK(hipMalloc(&b->keys_out, (size_t)n * sizeof(unsigned long long)));
+    LB_CK(hipMalloc(&b->leaf_parent, (size_t)n * sizeof(int)));
+    LB_CK(hipMalloc(&b->flags, (size_t)n * sizeof(uint32_t)));
+    size_t tmp = 0;
+    LB_CK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, b->keys_in, b->keys_out, (int)n, 0, 62, stream));
+    LB_CK(hipMalloc(&b->sort_tmp, tmp ? tmp : 16));
+    b->sort_tmp_bytes = tmp;
+    b->cap = n;
+    return hipSuccess;
+}
+
+static void read_info(const uint32_t* hdr, uint32_t depth, float ms, LbvhGpuInfo* info)
+{
+    info->build_ms = ms;
+    info->depth = depth;
+    float smax = 0.0f;
+    for (int a = 0; a < 3; a++) {
+        info->bounds_min[a] = ord2f(hdr[6 + a]);
+        info->bounds_max[a] = ord2f(hdr[9 + a]);
+        smax = std::fmax(smax, std::fmax(std::fabs(info->bounds_min[a]), std::fabs(info->bounds_max[a])));
+    }
+    info->pad = smax * 7.62939453125e-06f;
+}
+
 hipError_t lbvh_gpu_build(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode* d_nodes, float4* d_sorted, uint32_t* d_sorted_id,
                           hipStream_t stream, LbvhGpuInfo* info)
 {
     if (!b || !d_sph || n == 0 || !d_sorted || !d_sorted_id || !info) return hipErrorInvalidValue;
-    if (n > b->cap) {
-        LB_CK(hipStreamSynchronize(stream));
-        free_buffers(b);
-        LB_CK(hipMalloc(&b->keys_in, (size_t)n * sizeof(unsigned long long)));
-        LB_CK(hipMalloc(&b->keys_out, (size_t)n * sizeof(unsigned long long)));
-        LB_CK(hipMalloc(&b->leaf_parent, (size_t)n * sizeof(int)));
-        LB_CK(hipMalloc(&b->flags, (size_t)n * sizeof(uint32_t)));
-        size_t tmp = 0;
-        LB_CK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, b->keys_in, b->keys_out, (int)n, 0, 62, stream));
-        LB_CK(hipMalloc(&b->sort_tmp, tmp ? tmp : 16));
-        b->sort_tmp_bytes = tmp;
-        b->cap = n;
-    }
+    LB_CK(ensure_capacity(b, n, stream));
     const uint32_t threads = 256;
     const uint32_t grid = (n + threads - 1) / threads < 4096u ? (n + threads - 1) / threads : 4096u;
     const uint32_t red_grid = grid < 512u ? grid : 512u;
@@ -388,15 +406,36 @@ hipError_t lbvh_gpu_build(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode
     LB_CK(hipStreamSynchronize(stream));
     float ms = 0;
     LB_CK(hipEventElapsedTime(&ms, b->e0, b->e1));
-    info->build_ms = ms;
-    info->depth = n > 1 ? hdr[12] : 0u;
-    float smax = 0.0f;
-    for (int a = 0; a < 3; a++) {
-        info->bounds_min[a] = ord2f(hdr[6 + a]);
-        info->bounds_max[a] = ord2f(hdr[9 + a]);
-        smax = std::fmax(smax, std::fmax(std::fabs(info->bounds_min[a]), std::fabs(info->bounds_max[a])));
-    }
-    info->pad = smax * 7.62939453125e-06f;
+    read_info(hdr, n > 1 ? hdr[12] : 0u, ms, info);
+    return hipSuccess;
+}
+
+// A topology built elsewhere (the host SAH builder): upload the records' links and the leaf order, then let the refit passes
+// -- topology-agnostic -- compute every box, exactly as a later lbvh_gpu_refit will.  `depth` bounds the passes for
+// n > kRefitSmall (the single-workgroup form finds the depth itself).
+hipError_t lbvh_gpu_adopt(LbvhGpu* b, const float4* d_sph, uint32_t n, const PtBvhNode* h_nodes, const uint32_t* h_sorted_id, uint32_t depth,
+                          PtBvhNode* d_nodes, float4* d_sorted, uint32_t* d_sorted_id, hipStream_t stream, LbvhGpuInfo* info)
+{
+    if (!b || !d_sph || n == 0 || !d_sorted || !d_sorted_id || !h_sorted_id || !info || (n > 1 && (!h_nodes || !d_nodes))) return hipErrorInvalidValue;
+    LB_CK(ensure_capacity(b, n, stream));
+    const uint32_t threads = 256;
+    const uint32_t grid = (n + threads - 1) / threads < 4096u ? (n + threads - 1) / threads : 4096u;
+    const uint32_t red_grid = grid < 512u ? grid : 512u;
+    LB_CK(hipEventRecord(b->e0, stream));
+    if (n > 1) LB_CK(hipMemcpyAsync(d_nodes, h_nodes, (size_t)(n - 1) * sizeof(PtBvhNode), hipMemcpyHostToDevice, stream));
+    LB_CK(hipMemcpyAsync(d_sorted_id, h_sorted_id, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(init_header_kernel, dim3(1), dim3(64), 0, stream, b->hdr);
+    hipLaunchKernelGGL(bounds_kernel, dim3(red_grid), dim3(threads), 0, stream, d_sph, n, b->hdr);
+    hipLaunchKernelGGL(gather_by_id_kernel, dim3(grid), dim3(threads), 0, stream, d_sph, d_sorted_id, n, d_sorted);
+    LB_CK(launch_refit(d_sorted, n, d_nodes, b->flags, b->hdr, depth, stream));
+    LB_CK(hipGetLastError());
+    LB_CK(hipEventRecord(b->e1, stream));
+    uint32_t hdr[kHdrWords];
+    LB_CK(hipMemcpyAsync(hdr, b->hdr, sizeof hdr, hipMemcpyDeviceToHost, stream));
+    LB_CK(hipStreamSynchronize(stream));
+    float ms = 0;
+    LB_CK(hipEventElapsedTime(&ms, b->e0, b->e1));
+    read_info(hdr, n > 1 ? depth : 0u, ms, info);
     return hipSuccess;
 }
 

@@ -40,7 +40,7 @@ typedef enum PtStatus {
     PT_ERR_NO_DEVICE = 2,
     PT_ERR_HIP = 3,
     PT_ERR_STATE = 4,       /* call order violated (e.g. render before build_accel) */
-    PT_ERR_UNSUPPORTED = 5, /* IsDIEnabled / Denoiser / environment texture requested */
+    PT_ERR_UNSUPPORTED = 5, /* Denoiser / cube-map environment light requested */
     PT_ERR_OOM = 6
 } PtStatus;
 
@@ -59,6 +59,8 @@ enum {
                                     (8.4 us host for a 3-kernel graph vs 10.6 us for three launches, slower end to end) */
     PT_FLAG_HOST_LBVH = 4u,      /* build the LBVH on the host instead of on the GPU (debug / A-B) */
     PT_FLAG_SPLIT_KERNELS = 8u,  /* separate traverse / shade kernels with a hit stream instead of the fused bounce kernel */
+    PT_FLAG_FAST_BUILD = 64u,    /* always build the device LBVH (the PREFER_FAST_BUILD analogue).  Default: scenes of up to 4096
+                                    spheres get a SAH topology built on the host (PREFER_FAST_TRACE, Source/Scene.ixx:247,283) */
     PT_FLAG_DEFAULT_STREAM = 32u, /* with stream == 0: run on the legacy default stream instead of a context-owned one */
     PT_FLAG_TWO_FRAMES_IN_FLIGHT = 16u /* frames in flight (same as PtConfig.frames_in_flight = 2; that field allows up to 8):
                                           consecutive render calls rotate over N internal streams ("lanes", each with its own
@@ -75,8 +77,10 @@ typedef struct PtAccelInfo {
     float bounds_min[3];
     float bounds_max[3];
     float build_ms;          /* device or host build time */
-    uint32_t _reserved;
+    uint32_t builder;        /* PT_BUILDER_*: which builder made the topology */
 } PtAccelInfo;
+
+enum { PT_BUILDER_DEVICE_LBVH = 0, PT_BUILDER_HOST_LBVH = 1, PT_BUILDER_HOST_SAH = 2 };
 
 typedef struct PtStats {
     uint64_t rays;              /* CastRay-equivalents traced, primaries included */
@@ -209,6 +213,8 @@ PtStatus pt_accel_download_order(PtContext *ctx, uint32_t *sorted_id, uint32_t c
 /* Host LBVH builder (the PT_FLAG_HOST_LBVH path), callable without a context or a GPU, for structural tests:
  * nodes[n-1], sorted_id[n]; returns the tree depth through *depth. */
 PtStatus pt_lbvh_build_host(const PtSphere *spheres, uint32_t n, PtBvhNode *nodes, uint32_t *sorted_id, uint32_t *depth);
+/* Host SAH builder (the topology pt_build_accel gives small scenes), same outputs. */
+PtStatus pt_sah_build_host(const PtSphere *spheres, uint32_t n, PtBvhNode *nodes, uint32_t *sorted_id, uint32_t *depth);
 /* Turn per-launch hipEvent profiling on/off (an event pair around every kernel launch, on the stream it runs on). */
 PtStatus pt_set_profiling(PtContext *ctx, int enabled);
 /* Sum of the per-launch event times recorded since profiling was switched on / last reset, over every render call

@@ -79,6 +79,34 @@ def test_host_lbvh_structure(dxrs, host):
     check_lbvh(dup, nodes, order, depth)
 
 
+def test_host_sah_structure(dxrs, host):
+    """the SAH topology pt_build_accel gives small scenes: the same structural invariants, a bounded depth on inputs that
+    invite chains (the traversal stack and the refit passes are sized by it), and determinism"""
+    lib = dxrs.load_hip()
+    for kind, count in ((dxrs.host.SCENE_SMALL, 0), (dxrs.host.SCENE_DEMO, 0), (dxrs.host.SCENE_PROCEDURAL, 4000)):
+        spheres, _, _ = host.scene(kind, seed=1, count=count)
+        nodes, order, depth = lib.lbvh_build_host(spheres, sah=True)
+        check_lbvh(spheres, nodes, order, depth)
+        n2, o2, d2 = lib.lbvh_build_host(spheres, sah=True)
+        assert d2 == depth and np.array_equal(o2, order) and nodes.tobytes() == n2.tobytes()
+        assert depth <= lib.lbvh_build_host(spheres)[2] + 2  # never meaningfully deeper than the Morton tree
+    one = np.zeros(1, dtype=dxrs.SPHERE_DTYPE); one["r"] = 1
+    nodes, order, depth = lib.lbvh_build_host(one, sah=True)
+    assert len(nodes) == 0 and list(order) == [0] and depth == 0
+    n = 1000
+    cases = {"duplicates": np.zeros(64, dtype=dxrs.SPHERE_DTYPE), "geometric": np.zeros(n, dtype=dxrs.SPHERE_DTYPE),
+             "concentric": np.zeros(300, dtype=dxrs.SPHERE_DTYPE), "two": np.zeros(2, dtype=dxrs.SPHERE_DTYPE), "three": np.zeros(3, dtype=dxrs.SPHERE_DTYPE)}
+    cases["duplicates"]["r"] = 0.5; cases["duplicates"]["cx"] = 1.0
+    cases["geometric"]["cx"] = 2.0 ** (np.arange(n) / 12.0); cases["geometric"]["r"] = cases["geometric"]["cx"] * 0.01  # 1-vs-rest splits all the way
+    cases["concentric"]["r"] = 1 + np.arange(300)
+    cases["two"]["r"] = 1; cases["two"]["cx"] = (0, 3)
+    cases["three"]["r"] = 1; cases["three"]["cy"] = (0, 3, 3)
+    for name, sp in cases.items():
+        nodes, order, depth = lib.lbvh_build_host(sp, sah=True)
+        check_lbvh(sp, nodes, order, depth)
+        assert depth <= 24 + int(np.ceil(np.log2(len(sp)))) + 1, name
+
+
 def check_lbvh(spheres, nodes, order, depth):
     n = len(spheres)
     assert len(nodes) == n - 1 and sorted(order) == list(range(n))  # every sphere in exactly one leaf slot

@@ -88,25 +88,60 @@ def candidates(spheres, o, d):
     return dist2 <= rr * rr
 
 
-@pytest.mark.parametrize("name,count", [("small", 0), ("demo", 0), ("procedural", 50000), ("procedural", 1 << 20)])
-def test_device_tree_structure(dxrs, host, name, count):
+@pytest.mark.parametrize("name,count,fast_build", [("small", 0, False), ("demo", 0, False), ("small", 0, True), ("demo", 0, True),
+                                                   ("procedural", 4000, False), ("procedural", 50000, False), ("procedural", 1 << 20, False)])
+def test_device_tree_structure(dxrs, host, name, count, fast_build):
+    """up to 4096 spheres: the host SAH topology with device-computed boxes (PT_FLAG_FAST_BUILD: the device LBVH); above: the
+    device LBVH.  Either way the tree on the device is, record for record and box for box, the one the host builder makes."""
+    t = dxrs.types
     kind = {"small": dxrs.host.SCENE_SMALL, "demo": dxrs.host.SCENE_DEMO, "procedural": dxrs.host.SCENE_PROCEDURAL}[name]
     spheres, materials, sd = host.scene(kind, seed=1, count=count)
-    r = dxrs.Renderer()
+    r = dxrs.Renderer(flags=t.PT_FLAG_FAST_BUILD if fast_build else 0)
     try:
         info = r.set_scene(spheres, materials, sd)
+        sah = len(spheres) <= 4096 and not fast_build
+        assert info.builder == (t.PT_BUILDER_HOST_SAH if sah else t.PT_BUILDER_DEVICE_LBVH)
         nodes, order = r.download_accel()
         if len(spheres) <= 100000:  # the Python invariant walk is O(n) with numpy per node: minutes at 2^20
             check_lbvh(spheres, nodes, order, info.depth)
         if name != "procedural":
             assert info.lds_resident == 1  # small scenes: whole BVH staged in LDS
-        # the device tree is the same tree the host builder produces
-        hn, ho, hd = dxrs.load_hip().lbvh_build_host(spheres)
+        hn, ho, hd = dxrs.load_hip().lbvh_build_host(spheres, sah=sah)
         assert hd == info.depth and np.array_equal(ho, order)
         for f in ("child0", "child1", "parent", "lo0", "hi0", "lo1", "hi1"):
-            assert np.array_equal(hn[f], nodes[f]), f  # device build == host build, boxes bit-for-bit
+            assert np.array_equal(hn[f], nodes[f]), f  # device == host, boxes bit-for-bit
     finally:
         r.close()
+
+
+def test_builders_give_identical_images(dxrs, host):
+    """any valid BVH returns the same closest hit, so the SAH topology, the device LBVH and the host LBVH render the same bits
+    (and count the same rays); a refit of the adopted SAH tree keeps that true after the spheres moved"""
+    t = dxrs.types
+    w, h = 320, 180
+    cam, gs = host.camera(w, h), t.graphics_settings(w, h, bounces=6, spp=2)
+    for kind, count in ((dxrs.host.SCENE_DEMO, 0), (dxrs.host.SCENE_PROCEDURAL, 3000)):
+        spheres, materials, sd = host.scene(kind, seed=0, count=count)
+        moved = spheres.copy(); moved["cy"] += 0.25 * np.sin(np.arange(len(spheres)))
+        frames = []
+        for flags in (0, t.PT_FLAG_FAST_BUILD, t.PT_FLAG_HOST_LBVH):
+            r = dxrs.Renderer(flags=flags)
+            try:
+                info = r.set_scene(spheres, materials, sd)
+                r.set_camera(cam); r.set_constants(gs)
+                img, st = r.render()
+                img2 = st2 = None
+                if flags != t.PT_FLAG_HOST_LBVH:  # pt_update_spheres needs the device builder
+                    r.update_spheres(moved)
+                    img2, st2 = r.render()
+                frames.append((info.builder, img, st.rays, img2, st2.rays if st2 else None))
+            finally:
+                r.close()
+        assert [f[0] for f in frames] == [t.PT_BUILDER_HOST_SAH, t.PT_BUILDER_DEVICE_LBVH, t.PT_BUILDER_HOST_LBVH]
+        for f in frames[1:]:
+            assert f[2] == frames[0][2] and np.array_equal(f[1].view(np.uint32), frames[0][1].view(np.uint32))
+        assert frames[1][4] == frames[0][4] and np.array_equal(frames[1][3].view(np.uint32), frames[0][3].view(np.uint32))
+        assert not np.array_equal(frames[0][3], frames[0][1])  # the move is visible
 
 
 def test_single_sphere_scene(dxrs, host, oracle):
