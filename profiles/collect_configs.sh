@@ -12,6 +12,8 @@ run --scene small --width 256 --height 256 --bounces 4 --steps 300 --warmup 30  
 run --steps 300 --warmup 30                                                                           # C2 (headline)
 run --steps 300 --warmup 30 --animate --no-cpu-baseline                                               # C2 animated (N2)
 run --steps 300 --warmup 30 --textures --no-cpu-baseline                                              # C2 textured (N1)
+run --steps 300 --warmup 30 --env-map --no-cpu-baseline                                               # C2 lit by the lat-long environment map (a18)
+run --steps 300 --warmup 30 --di --no-cpu-baseline                                                    # C2 with sphere-light direct illumination (N4)
 run --width 3840 --height 2160 --spp 16 --steps 20 --warmup 3 --cpu-row-step 16                       # C3
 run --width 3840 --height 2160 --spp 64 --bounces 16 --steps 6 --warmup 2 --no-cpu-baseline           # C4 on one GPU
 run --scene procedural --steps 40 --warmup 5                                                          # C5
