@@ -86,6 +86,7 @@ struct PtContext {
 
     // textures (row N1): table of linear float4 images + per-sphere map indices and rotations
     std::vector<float4*> d_tex_images;
+    std::vector<std::pair<uint32_t, uint32_t>> tex_dims;  // width, height of every table entry
     TexView* d_tex = nullptr;
     uint32_t* d_tex_maps = nullptr;  // n * 8
     float4* d_rot = nullptr;         // n
@@ -217,6 +218,7 @@ void free_textures(PtContext* c)
 {
     for (auto& img : c->d_tex_images) free_dev(img);
     c->d_tex_images.clear();
+    c->tex_dims.clear();
     free_dev(c->d_tex); free_dev(c->d_tex_maps); free_dev(c->d_rot);
     c->has_textures = false;
 }
@@ -246,6 +248,7 @@ SceneView make_scene_view(const PtContext* c, const Lane* L = nullptr)
     for (int i = 0; i < 4; i++) sv.env[i] = c->sd.EnvironmentLightColor[i];
     if (c->has_textures) { sv.tex = c->d_tex; sv.tex_maps = c->d_tex_maps; sv.rot = c->d_rot; }
     sv.env_tex = c->sd.EnvironmentLightTextureDescriptor;  // ~0u == kNoTexture; render_common has checked it against the table
+    sv.env_cube = c->sd.IsEnvironmentLightTextureCubeMap ? 1u : 0u;
     for (int r = 0; r < 3; r++)
         for (int k = 0; k < 3; k++) sv.env_xf[3 * r + k] = c->sd.EnvironmentLightTransform[4 * r + k];
     sv.lights = c->d_lights; sv.n_lights = c->n_lights;
@@ -349,8 +352,14 @@ void sum_events(PtContext* c, size_t begin, size_t end, PtStats* stats)
 PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, float4* out, PtStats* stats)
 {
     const uint32_t bounces = c->gs.Bounces, spp = c->gs.SamplesPerPixel;
-    if (c->sd.EnvironmentLightTextureDescriptor != ~0u && (!c->has_textures || c->sd.EnvironmentLightTextureDescriptor >= c->d_tex_images.size()))
-        return fail(c, PT_ERR_STATE, "SceneData.EnvironmentLightTextureDescriptor names a texture the table of pt_set_textures does not hold (call pt_set_textures after pt_set_scene)");
+    if (const uint32_t env = c->sd.EnvironmentLightTextureDescriptor; env != ~0u) {
+        const size_t n_faces = c->sd.IsEnvironmentLightTextureCubeMap ? 6 : 1;
+        if (!c->has_textures || (size_t)env + n_faces > c->tex_dims.size())
+            return fail(c, PT_ERR_STATE, "SceneData.EnvironmentLightTextureDescriptor names a texture the table of pt_set_textures does not hold (call pt_set_textures after pt_set_scene; a cube map takes six consecutive entries)");
+        for (size_t f = 0; f < n_faces; f++)
+            if (n_faces == 6 && (c->tex_dims[env + f].first != c->tex_dims[env].first || c->tex_dims[env + f].second != c->tex_dims[env].first))
+                return fail(c, PT_ERR_STATE, "SceneData.EnvironmentLightTextureDescriptor: the six faces of a cube map must be square and of one size");
+    }
     const size_t max_iters = (size_t)spp * bounces + 1;  // passes if everything ran as wavefront
     const size_t wf_cap = spp > 1 ? max_iters : std::min<size_t>(max_iters, 64);
     // LDS-resident BVH: fused trace+shade passes (traversal is cheap, the hit stream is pure overhead).  BVH in global
@@ -673,8 +682,6 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
     if (!c) return PT_ERR_INVALID_ARG;
     if (!spheres || !materials || !sd || n == 0) return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: null pointer or n == 0");
     if (n > (1u << 30)) return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: too many spheres");
-    if (sd->EnvironmentLightTextureDescriptor != ~0u && sd->IsEnvironmentLightTextureCubeMap)
-        return fail(c, PT_ERR_UNSUPPORTED, "cube-map environment lights are not supported (lat-long maps only: IsEnvironmentLightTextureCubeMap must be 0)");
     for (uint32_t i = 0; i < n; i++)
         if (!(spheres[i].r > 0.0f) || !std::isfinite(spheres[i].r) || !std::isfinite(spheres[i].cx) || !std::isfinite(spheres[i].cy) || !std::isfinite(spheres[i].cz))
             return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: sphere " + std::to_string(i) + " has a non-finite centre or non-positive radius");
@@ -1073,6 +1080,7 @@ PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_tex
         PT_HIP(c, hipMalloc(&c->d_tex_images[t], count * sizeof(float4)));
         PT_HIP(c, hipMemcpy(c->d_tex_images[t], src, count * sizeof(float4), hipMemcpyHostToDevice));
         views[t].texels = c->d_tex_images[t]; views[t].w = tx.Width; views[t].h = tx.Height;
+        c->tex_dims.emplace_back(tx.Width, tx.Height);
     }
     PT_HIP(c, hipMalloc(&c->d_tex, n_textures * sizeof(TexView)));
     PT_HIP(c, hipMemcpy(c->d_tex, views.data(), n_textures * sizeof(TexView), hipMemcpyHostToDevice));

@@ -48,7 +48,8 @@ struct SceneView {
     const TexView* tex;         // texture table
     const uint32_t* tex_maps;   // per sphere: 7 texture indices (TextureMapType order) + 1 "has any" flag
     const float4* rot;          // per sphere: object rotation quaternion (x, y, z, w)
-    uint32_t env_tex;           // lat-long environment map: index into tex, kNoTexture = EnvironmentLightColor / sky
+    uint32_t env_tex;           // environment map: index into tex, kNoTexture = EnvironmentLightColor / sky
+    uint32_t env_cube;          // 1: tex[env_tex .. env_tex + 5] are the faces of a cube map; 0: tex[env_tex] is a lat-long map
     float env_xf[9];            // upper 3x3 of SceneData.EnvironmentLightTransform, row-major
     // row N4 (sphere-light direct illumination): ids of the emissive spheres, in id order
     const uint32_t* lights;

@@ -441,7 +441,8 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
         HitFrame hf;
         if (id == kMissId) {
             f3 env;
-            if (kTex && sv.env_tex != kNoTexture) env = environment_texture(sv.tex[sv.env_tex], sv.env_xf, ps.d);
+            if (kTex && sv.env_tex != kNoTexture)
+                env = sv.env_cube ? environment_cube(sv.tex + sv.env_tex, sv.env_xf, ps.d) : environment_texture(sv.tex[sv.env_tex], sv.env_xf, ps.d);
             else env = environment_color(sv.env[0], sv.env[1], sv.env[2], sv.env[3], ps.d);
             if (ps.bounce == 0) {  // primary miss: pixel = environment (GBufferGeneration.hlsl:223-227; Raytracing.hlsl:249-252)
                 out[slot_to_pixel(pm, slot).out_index] = make_float4(env.x, env.y, env.z, 1.0f);

@@ -116,6 +116,55 @@ PT_HD f3 environment_texture(const TexView& tv, const float* m, f3 d)
     return make_f3(s[0], s[1], s[2]);
 }
 
+// ... and for a cube map, `TextureCube::SampleLevel(sampler, d, 0)` (spec S9, build-frozen): the face is the axis of largest
+// magnitude (ties: z over y over x), faces in D3D order +X, -X, +Y, -Y, +Z, -Z, face coordinates (sc, tc) / |major| mapped
+// to [0, 1]^2 by the D3D table below, level-0 bilinear INSIDE the face with clamp addressing (hardware filters across face
+// edges; the difference is confined to the outermost half texel of a face).
+struct CubeCoord { uint32_t face; f2 uv; };
+
+PT_HD CubeCoord cube_face_uv(f3 d)
+{
+    const float ax = pt_abs(d.x), ay = pt_abs(d.y), az = pt_abs(d.z);
+    CubeCoord c;
+    float sc, tc, ma;
+    if (az >= ax && az >= ay) { c.face = d.z < 0.0f ? 5u : 4u; sc = d.z < 0.0f ? -d.x : d.x; tc = -d.y; ma = az; }
+    else if (ay >= ax)        { c.face = d.y < 0.0f ? 3u : 2u; sc = d.x; tc = d.y < 0.0f ? -d.z : d.z; ma = ay; }
+    else                      { c.face = d.x < 0.0f ? 1u : 0u; sc = d.x < 0.0f ? d.z : -d.z; tc = -d.y; ma = ax; }
+    c.uv.x = pt_fma(sc / ma, 0.5f, 0.5f);
+    c.uv.y = pt_fma(tc / ma, 0.5f, 0.5f);
+    return c;
+}
+
+PT_HD uint32_t clamp_index(int i, uint32_t n) { return i < 0 ? 0u : ((uint32_t)i >= n ? n - 1u : (uint32_t)i); }
+
+PT_HD void sample_bilinear_clamp(const TexView& tv, f2 uv, float out[4])
+{
+    float u = uv.x, v = uv.y;
+    if (!(pt_abs(u) < 65536.0f)) u = 0.0f;  // NaN direction (0/0): texel 0
+    if (!(pt_abs(v) < 65536.0f)) v = 0.0f;
+    const float x = pt_fma(u, (float)tv.w, -0.5f), y = pt_fma(v, (float)tv.h, -0.5f);
+    const float xf = pt_floor(x), yf = pt_floor(y);
+    const float fx = x - xf, fy = y - yf;
+    const uint32_t x0 = clamp_index((int)xf, tv.w), x1 = clamp_index((int)xf + 1, tv.w);
+    const uint32_t y0 = clamp_index((int)yf, tv.h), y1 = clamp_index((int)yf + 1, tv.h);
+    const float4 c00 = tv.texels[(size_t)y0 * tv.w + x0], c10 = tv.texels[(size_t)y0 * tv.w + x1];
+    const float4 c01 = tv.texels[(size_t)y1 * tv.w + x0], c11 = tv.texels[(size_t)y1 * tv.w + x1];
+    out[0] = lerp1(lerp1(c00.x, c10.x, fx), lerp1(c01.x, c11.x, fx), fy);
+    out[1] = lerp1(lerp1(c00.y, c10.y, fx), lerp1(c01.y, c11.y, fx), fy);
+    out[2] = lerp1(lerp1(c00.z, c10.z, fx), lerp1(c01.z, c11.z, fx), fy);
+    out[3] = lerp1(lerp1(c00.w, c10.w, fx), lerp1(c01.w, c11.w, fx), fy);
+}
+
+// faces: six consecutive entries of the texture table
+PT_HD f3 environment_cube(const TexView* faces, const float* m, f3 d)
+{
+    const f3 r = normalize(make_f3(dot(make_f3(m[0], m[1], m[2]), d), dot(make_f3(m[3], m[4], m[5]), d), dot(make_f3(m[6], m[7], m[8]), d)));
+    const CubeCoord c = cube_face_uv(r);
+    float s[4];
+    sample_bilinear_clamp(faces[c.face], c.uv, s);
+    return make_f3(s[0], s[1], s[2]);
+}
+
 // Geometry::UnpackLocalNormal (MathLib, un-vendored; recollection): xy = s * 255/127 - 1, z = Sqrt01(1 - |xy|^2)
 PT_HD f3 unpack_local_normal(float sx, float sy)
 {

@@ -67,9 +67,13 @@ struct Scene {
                 info.Descriptor = it->second;
             }
         m_environmentDescriptor = ~0u;
+        m_environmentIsCubeMap = false;
         if (!Desc.EnvironmentLight.Texture.empty()) {  // Scene.ixx:130-133
-            m_textures.emplace_back(m_loader ? m_loader(Desc.EnvironmentLight.Texture, EnvironmentLightTexture) : DefaultTextureLoader(Desc.EnvironmentLight.Texture, EnvironmentLightTexture));
-            m_environmentDescriptor = static_cast<uint32_t>(m_textures.size() - 1);
+            auto texture = m_loader ? m_loader(Desc.EnvironmentLight.Texture, EnvironmentLightTexture) : DefaultTextureLoader(Desc.EnvironmentLight.Texture, EnvironmentLightTexture);
+            m_environmentDescriptor = static_cast<uint32_t>(m_textures.size());
+            m_environmentIsCubeMap = texture.IsCubeMap();
+            if (m_environmentIsCubeMap) for (auto& face : texture.Faces) m_textures.emplace_back(std::move(face));  // six consecutive table entries
+            else m_textures.emplace_back(std::move(texture));
         }
         Refresh();
     }
@@ -107,6 +111,7 @@ struct Scene {
         PtSceneData sd{};
         sd.IsStatic = 1;
         sd.EnvironmentLightTextureDescriptor = m_environmentDescriptor;
+        sd.IsEnvironmentLightTextureCubeMap = m_environmentIsCubeMap ? 1u : 0u;
         sd.EnvironmentLightColor[0] = Desc.EnvironmentLight.Color.x;
         sd.EnvironmentLightColor[1] = Desc.EnvironmentLight.Color.y;
         sd.EnvironmentLightColor[2] = Desc.EnvironmentLight.Color.z;
@@ -126,6 +131,7 @@ private:
     std::vector<Texture> m_textures;
     std::vector<PtObjectTextures> m_objectTextures;
     uint32_t m_environmentDescriptor = ~0u;
+    bool m_environmentIsCubeMap = false;
     TextureLoader m_loader;
 };
 

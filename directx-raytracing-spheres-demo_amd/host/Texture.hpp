@@ -24,6 +24,9 @@ struct Texture {
     bool ForceSRGB = false;           // colour data: sampled as DXGI_FORMAT_R8G8B8A8_UNORM_SRGB
     std::vector<uint8_t> Pixels;      // Width * Height * 4, row-major RGBA
     std::vector<float> HDRPixels;     // or: Width * Height * 4 linear floats (an .exr / .hdr environment map); Pixels empty
+    std::vector<Texture> Faces;       // or: the six square faces of a cube map (+X, -X, +Y, -Y, +Z, -Z), this entry itself empty
+
+    bool IsCubeMap() const noexcept { return Faces.size() == 6; }  // Texture::IsCubeMap (Source/App.cpp:984)
 
     bool IsHDR() const noexcept { return !HDRPixels.empty(); }
     uint32_t Format() const noexcept { return IsHDR() ? PT_TEXTURE_RGBA32_FLOAT : ForceSRGB ? PT_TEXTURE_RGBA8_UNORM_SRGB : PT_TEXTURE_RGBA8_UNORM; }

@@ -39,6 +39,15 @@ class TextureSet:
         self.images.append((np.ascontiguousarray(a), TEXTURE_RGBA32_FLOAT))
         return len(self.images) - 1
 
+    def add_cube(self, faces):
+        """six square float32 (s, s, 3|4) faces in D3D order (+X, -X, +Y, -Y, +Z, -Z) -> index of the first one: the
+        descriptor of a cube-map environment light (IsEnvironmentLightTextureCubeMap = 1)"""
+        assert len(faces) == 6
+        first = self.add_hdr_image(faces[0])
+        for f in faces[1:]:
+            self.add_hdr_image(f)
+        return first
+
     def assign(self, sphere, map_type, texture_index):
         self.maps[sphere, map_type] = texture_index
 
@@ -129,6 +138,23 @@ def sky_latlong(w, h, seed=0, sun_dir=(0.4, 0.6, 0.7), sun_radiance=40.0):
     s = np.asarray(sun_dir, np.float64); s = s / np.linalg.norm(s)
     img = img + sun_radiance * np.clip((d @ s - 0.995) / 0.005, 0, 1)[..., None] ** 2
     return img.astype(np.float32)
+
+
+def cube_directions(size):
+    """unit direction through every texel centre of the six faces, (6, size, size, 3) float64: the inverse of the D3D face
+    table (face, u, v) -> (sc, tc) = (2u - 1, 2v - 1)"""
+    t = (np.arange(size) + 0.5) / size * 2 - 1
+    tc, sc = np.meshgrid(t, t, indexing="ij")  # rows = v (tc), columns = u (sc)
+    one = np.ones_like(sc)
+    d = np.stack([np.stack([one, -tc, -sc], -1), np.stack([-one, -tc, sc], -1),     # +X: sc = -z, tc = -y; -X: sc = +z
+                  np.stack([sc, one, tc], -1), np.stack([sc, -one, -tc], -1),       # +Y: sc = x, tc = z;   -Y: tc = -z
+                  np.stack([sc, -tc, one], -1), np.stack([-sc, -tc, -one], -1)])    # +Z: sc = x, tc = -y;  -Z: sc = -x
+    return d / np.linalg.norm(d, axis=-1, keepdims=True)
+
+
+def cube_from_function(size, fn):
+    """six faces (size, size, 3) float32 of fn(directions (..., 3)) -> (..., 3)"""
+    return [fn(d).astype(np.float32) for d in cube_directions(size)]
 
 
 def load_image(path, srgb_hint=None):

@@ -40,7 +40,7 @@ typedef enum PtStatus {
     PT_ERR_NO_DEVICE = 2,
     PT_ERR_HIP = 3,
     PT_ERR_STATE = 4,       /* call order violated (e.g. render before build_accel) */
-    PT_ERR_UNSUPPORTED = 5, /* Denoiser / cube-map environment light requested */
+    PT_ERR_UNSUPPORTED = 5, /* Denoiser requested, a second texture-coordinate set, ... */
     PT_ERR_OOM = 6
 } PtStatus;
 
@@ -177,8 +177,8 @@ PtStatus pt_unpack_tiles_rgb(PtContext *ctx, const void *packed_device, uint64_t
  *   rotations              n unit quaternions (x, y, z, w): object -> world rotation of each sphere, NULL = identity
  * n_textures == 0 removes all textures.  Every kernel that shades has a textured variant, selected per launch.
  * The table is also where SceneData.EnvironmentLightTextureDescriptor points (row a18's texture branch,
- * ShadingHelpers.hlsli:13-24: a lat-long map, usually PT_TEXTURE_RGBA32_FLOAT); pt_render* fails with PT_ERR_STATE while the
- * scene names an environment texture the table does not hold.
+ * ShadingHelpers.hlsli:13-24: a lat-long map, or the first of the six faces of a cube map; usually PT_TEXTURE_RGBA32_FLOAT);
+ * pt_render* fails with PT_ERR_STATE while the scene names an environment texture the table does not hold.
  * pt_update_rotations replaces the quaternions (Earth's spin, the Moon's tidal lock: Source/MyScene.ixx:240-291); it
  * waits for the frames in flight. */
 PtStatus pt_set_textures(PtContext *ctx, const PtTexture *textures, uint32_t n_textures,

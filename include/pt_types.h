@@ -72,10 +72,11 @@ typedef struct PtCamera {
 
 /* Source/CommonShaderData.ixx:15-20. EnvironmentLightColor.a < 0 selects the
  * procedural sky (Shaders/ShadingHelpers.hlsli:25-29).  EnvironmentLightTextureDescriptor
- * != ~0u selects a lat-long environment map (ShadingHelpers.hlsli:13-24): it indexes the
+ * != ~0u selects an environment map (ShadingHelpers.hlsli:13-24): it indexes the
  * PtTexture table given to pt_set_textures (this path's descriptor heap), the lookup
- * direction is rotated by the upper 3x3 of EnvironmentLightTransform.  Cube maps
- * (IsEnvironmentLightTextureCubeMap) are not supported. */
+ * direction is rotated by the upper 3x3 of EnvironmentLightTransform.  With
+ * IsEnvironmentLightTextureCubeMap the descriptor names the first of six consecutive
+ * square faces of one size in D3D order (+X, -X, +Y, -Y, +Z, -Z); else a lat-long map. */
 typedef struct PtSceneData {
     uint32_t IsStatic;                          /*  0 */
     uint32_t IsEnvironmentLightTextureCubeMap;  /*  4 */

@@ -64,6 +64,7 @@ def declare_leaf_api(lib, prefix):
     fn("atan2", f, [f, f])
     fn("sphere_uv", None, [pf, pf])
     fn("latlong_uv", None, [pf, pf])
+    fn("cube_face_uv", C.c_uint32, [pf, pf])
     fn("sphere_tangent", None, [pf, pf])
     fn("quat_rotate", None, [pf, pf, pf])
     fn("perturb_normal", None, [pf, pf, f, f, pf])

@@ -922,13 +922,52 @@ void oracle_latlong_uv(const float d[3], float uv[2])
     uv[1] = oracle_atan2(sqrtf(f_max(FMA(-d[1], d[1], 1.0f), 0.0f)), d[1]) * 0.31830988618379067154f;
 }
 
+/* TextureCube::SampleLevel(sampler, d, 0) (ShadingHelpers.hlsli:17-21), spec S9: face = axis of largest magnitude (ties z over
+ * y over x), D3D face order +X -X +Y -Y +Z -Z and face coordinates, level-0 bilinear inside the face, clamp addressing. */
+uint32_t oracle_cube_face_uv(const float d[3], float uv[2])
+{
+    float ax = f_abs(d[0]), ay = f_abs(d[1]), az = f_abs(d[2]);
+    uint32_t face;
+    float sc, tc, ma;
+    if (az >= ax && az >= ay) { face = d[2] < 0.0f ? 5u : 4u; sc = d[2] < 0.0f ? -d[0] : d[0]; tc = -d[1]; ma = az; }
+    else if (ay >= ax)        { face = d[1] < 0.0f ? 3u : 2u; sc = d[0]; tc = d[1] < 0.0f ? -d[2] : d[2]; ma = ay; }
+    else                      { face = d[0] < 0.0f ? 1u : 0u; sc = d[0] < 0.0f ? d[2] : -d[2]; tc = -d[1]; ma = ax; }
+    uv[0] = FMA(sc / ma, 0.5f, 0.5f);
+    uv[1] = FMA(tc / ma, 0.5f, 0.5f);
+    return face;
+}
+
+static uint32_t clamp_index(int i, uint32_t n) { return i < 0 ? 0u : ((uint32_t)i >= n ? n - 1u : (uint32_t)i); }
+
+static void sample_bilinear_clamp(const tex_ctx *c, uint32_t index, const float uv[2], float out[4])
+{
+    const PtTexture *tx = &c->t->textures[index];
+    float u = uv[0], v = uv[1];
+    if (!(f_abs(u) < 65536.0f)) u = 0.0f;
+    if (!(f_abs(v) < 65536.0f)) v = 0.0f;
+    float x = FMA(u, (float)tx->Width, -0.5f), y = FMA(v, (float)tx->Height, -0.5f);
+    float xf = floorf(x), yf = floorf(y);
+    float fx = x - xf, fy = y - yf;
+    uint32_t x0 = clamp_index((int)xf, tx->Width), x1 = clamp_index((int)xf + 1, tx->Width);
+    uint32_t y0 = clamp_index((int)yf, tx->Height), y1 = clamp_index((int)yf + 1, tx->Height);
+    float c00[4], c10[4], c01[4], c11[4];
+    fetch_texel(c, tx, x0, y0, c00); fetch_texel(c, tx, x1, y0, c10);
+    fetch_texel(c, tx, x0, y1, c01); fetch_texel(c, tx, x1, y1, c11);
+    for (int k = 0; k < 4; k++) out[k] = lerp1(lerp1(c00[k], c10[k], fx), lerp1(c01[k], c11[k], fx), fy);
+}
+
 static v3 environment_texture(const tex_ctx *tc, const PtSceneData *sd, v3 d)
 {
     const float *m = sd->EnvironmentLightTransform;
     v3 r = v_normalize(V3(v_dot(V3(m[0], m[1], m[2]), d), v_dot(V3(m[4], m[5], m[6]), d), v_dot(V3(m[8], m[9], m[10]), d)));
     float dir[3] = { r.x, r.y, r.z }, uv[2], s[4];
-    oracle_latlong_uv(dir, uv);
-    sample_bilinear(tc, sd->EnvironmentLightTextureDescriptor, uv, s);
+    if (sd->IsEnvironmentLightTextureCubeMap) {
+        uint32_t face = oracle_cube_face_uv(dir, uv);
+        sample_bilinear_clamp(tc, sd->EnvironmentLightTextureDescriptor + face, uv, s);
+    } else {
+        oracle_latlong_uv(dir, uv);
+        sample_bilinear(tc, sd->EnvironmentLightTextureDescriptor, uv, s);
+    }
     return V3(s[0], s[1], s[2]);
 }
 
@@ -1287,7 +1326,6 @@ static int validate(const PtSceneData *sd, const PtGraphicsSettings *gs, uint32_
     if (gs->RenderSize[0] == 0 || gs->RenderSize[1] == 0 || gs->SamplesPerPixel == 0) return 2;
     if (gs->RenderSize[0] > 65535u || gs->RenderSize[1] > 65535u) return 2; /* (px<<16)|py seed */
     if (gs->Denoiser) return 3;
-    if (sd->EnvironmentLightTextureDescriptor != 0xFFFFFFFFu && sd->IsEnvironmentLightTextureCubeMap) return 4; /* lat-long maps only */
     return 0;
 }
 
@@ -1322,8 +1360,12 @@ int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials,
     int err = validate(scene, gs, n);
     if (err) return err;
     if ((err = validate_textures(textures, n)) != 0) return err;
-    if (scene->EnvironmentLightTextureDescriptor != 0xFFFFFFFFu && (!textures || scene->EnvironmentLightTextureDescriptor >= textures->n_textures))
-        return 4; /* the descriptor indexes the texture table */
+    if (scene->EnvironmentLightTextureDescriptor != 0xFFFFFFFFu) { /* the descriptor indexes the texture table; a cube map = 6 square faces */
+        const uint32_t e = scene->EnvironmentLightTextureDescriptor, nf = scene->IsEnvironmentLightTextureCubeMap ? 6u : 1u;
+        if (!textures || (uint64_t)e + nf > textures->n_textures) return 4;
+        for (uint32_t f = 0; f < nf && nf == 6u; f++)
+            if (textures->textures[e + f].Width != textures->textures[e].Width || textures->textures[e + f].Height != textures->textures[e].Width) return 4;
+    }
     tex_ctx tc;
     const int textured = textures && textures->n_textures > 0;
     if (textured) tex_ctx_init(&tc, textures);

@@ -58,6 +58,7 @@ int oracle_sample_sphere_cone(const float P[3], const float C[3], float r, float
 float oracle_atan2(float y, float x);
 void oracle_sphere_uv(const float n[3], float uv[2]);
 void oracle_latlong_uv(const float d[3], float uv[2]); /* Math::ToLatLongCoordinate (Math.hlsli:29-33), row a18's texture branch */
+uint32_t oracle_cube_face_uv(const float d[3], float uv[2]); /* TextureCube face selection + face coordinates (spec S9); returns the face */
 void oracle_sphere_tangent(const float n[3], float t[3]);
 void oracle_quat_rotate(const float q[4], const float v[3], float out[3]);
 void oracle_sample_texture(const OracleTextures *t, uint32_t index, const float uv[2], float out[4]);

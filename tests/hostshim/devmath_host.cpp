@@ -83,6 +83,7 @@ int dev_sample_sphere_cone(const float P[3], const float C[3], float r, float u1
 
 // ---- row N1 leaves
 float dev_atan2(float y, float x) { return atan2_spec(y, x); }
+uint32_t dev_cube_face_uv(const float d[3], float uv[2]) { CubeCoord c = cube_face_uv(make_f3(d[0], d[1], d[2])); uv[0] = c.uv.x; uv[1] = c.uv.y; return c.face; }
 void dev_latlong_uv(const float d[3], float uv[2]) { f2 r = latlong_uv(make_f3(d[0], d[1], d[2])); uv[0] = r.x; uv[1] = r.y; }
 void dev_sphere_uv(const float n[3], float uv[2]) { f2 r = sphere_uv(make_f3(n[0], n[1], n[2])); uv[0] = r.x; uv[1] = r.y; }
 void dev_sphere_tangent(const float n[3], float t[3]) { f3 r = sphere_tangent(make_f3(n[0], n[1], n[2])); t[0] = r.x; t[1] = r.y; t[2] = r.z; }

@@ -143,13 +143,92 @@ def test_oracle_rejects_bad_environment_descriptors(dxrs, host, oracle):
         oracle.render(spheres, materials, set_env(sd, 1), cam, gs, textures=ts)  # out of range
     cube = set_env(sd, 0); cube.IsEnvironmentLightTextureCubeMap = 1
     with pytest.raises(Exception):
-        oracle.render(spheres, materials, cube, cam, gs, textures=ts)
+        oracle.render(spheres, materials, cube, cam, gs, textures=ts)  # a cube map needs six table entries
+    for k in range(4):
+        ts.add_hdr_image(np.ones((2, 2, 3), np.float32))
+    ts.add_hdr_image(np.ones((2, 3, 3), np.float32))
+    with pytest.raises(Exception):
+        oracle.render(spheres, materials, cube, cam, gs, textures=ts)  # ... square and of one size
+
+
+# ---- cube maps ---------------------------------------------------------------------------------------------------------
+
+def set_cube(sd, descriptor, matrix=None):
+    out = set_env(sd, descriptor, matrix)
+    out.IsEnvironmentLightTextureCubeMap = 1
+    return out
+
+
+def test_cube_face_convention_and_parity(oracle, dev):
+    def face_uv(fn, d):
+        uv = (C.c_float * 2)()
+        return int(fn(fa(*d), uv)), np.array(uv[:], dtype=np.float32)
+    o = lambda d: face_uv(oracle.lib.oracle_cube_face_uv, d)
+    # the axes hit the centres of the faces, in D3D order +X -X +Y -Y +Z -Z
+    for face, axis in enumerate([(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]):
+        f, uv = o(axis)
+        assert f == face and np.allclose(uv, 0.5)
+    # D3D face coordinates: on +X u runs towards -z and v towards -y; on +Y u towards +x, v towards +z; on +Z u towards +x, v towards -y
+    assert np.allclose(o((1, 0.5, 0))[1], (0.5, 0.25)) and np.allclose(o((1, 0, 0.5))[1], (0.25, 0.5))
+    assert np.allclose(o((-1, 0, 0.5))[1], (0.75, 0.5))
+    assert np.allclose(o((0.5, 1, 0))[1], (0.75, 0.5)) and np.allclose(o((0, 1, 0.5))[1], (0.5, 0.75))
+    assert np.allclose(o((0, -1, 0.5))[1], (0.5, 0.25))
+    assert np.allclose(o((0.5, 0, 1))[1], (0.75, 0.5)) and np.allclose(o((0, 0.5, 1))[1], (0.5, 0.25))
+    assert np.allclose(o((0.5, 0, -1))[1], (0.25, 0.5))
+    # ties: z over y over x
+    assert o((1, 1, 1))[0] == 4 and o((1, 1, -1))[0] == 5 and o((1, 1, 0.5))[0] == 2 and o((1, -1, 0))[0] == 3
+    rng = np.random.default_rng(12)
+    dirs = np.concatenate([unit(rng, 4000), [[1, 1, 1], [-1, 1, -1], [0, 0, 0], [1e-30, 0, 0], [1, -1, 0.999999]]]).astype(np.float32)
+    from dxrs_amd.textures import cube_directions
+    for d in dirs:
+        (f1, uv1), (f2, uv2) = o(d), face_uv(dev.dev_cube_face_uv, d)
+        assert f1 == f2 and np.array_equal(bits(uv1), bits(uv2))
+    # cube_directions is the inverse map: the direction through texel (face, y, x) lands on that texel's centre
+    size = 4
+    cd = cube_directions(size)
+    for face in range(6):
+        for y in range(size):
+            for x in range(size):
+                f, uv = o(cd[face, y, x].astype(np.float32))
+                assert f == face and np.allclose(uv, ((x + 0.5) / size, (y + 0.5) / size), atol=1e-6)
+
+
+def test_oracle_cube_map_consistency(dxrs, host, oracle):
+    """a one-colour cube == the constant-colour branch, bit for bit; a cube and a lat-long map made from the same smooth
+    function of the direction light the scene alike"""
+    from dxrs_amd import textures as T
+    spheres, materials, sd = small_scene(dxrs, host)
+    w, h = 64, 48
+    cam, gs = host.camera(w, h), dxrs.types.graphics_settings(w, h, bounces=0)
+    colour = np.array([0.5, 2.25, 1.0], np.float32)
+    ts = T.TextureSet(len(spheres))
+    first = ts.add_cube([np.tile(colour, (3, 3, 1))] * 6)
+    const = copy.copy(sd)
+    for k in range(3):
+        const.EnvironmentLightColor[k] = float(colour[k])
+    const.EnvironmentLightColor[3] = 1.0
+    gs4 = dxrs.types.graphics_settings(w, h, bounces=4, spp=2)
+    ref, st = oracle.render(spheres, materials, const, cam, gs4, threads=4)
+    rng = np.random.default_rng(5)
+    img, st2 = oracle.render(spheres, materials, set_cube(sd, first, random_rotation(rng)), cam, gs4, threads=4, textures=ts)
+    assert st.rays == st2.rays and np.array_equal(bits(img), bits(ref))
+    fn = lambda d: np.stack([0.5 + 0.4 * d[..., 0], 0.5 + 0.4 * d[..., 1] * d[..., 2], 1.0 + 0.5 * d[..., 2]], -1)
+    ts2 = T.TextureSet(len(spheres))
+    cube = ts2.add_cube(T.cube_from_function(64, fn))
+    W, H = 256, 128
+    v, u = np.meshgrid((np.arange(H) + 0.5) / H, (np.arange(W) + 0.5) / W, indexing="ij")
+    theta, phi = v * np.pi, (2 * u - 1) * np.pi
+    lat = ts2.add_hdr_image(fn(np.stack([np.sin(theta) * np.sin(phi), np.cos(theta), np.sin(theta) * np.cos(phi)], -1)))
+    m = random_rotation(rng)
+    a, _ = oracle.render(spheres, materials, set_cube(sd, cube, m), cam, gs, threads=4, textures=ts2)
+    b, _ = oracle.render(spheres, materials, set_env(sd, lat, m), cam, gs, threads=4, textures=ts2)
+    assert np.allclose(a, b, rtol=0, atol=0.02)
 
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_ENV_SEEDS", "10"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_ENV_SEEDS", "15"))))
 def test_gpu_environment_map_matches_oracle(dxrs, host, oracle, renderer, seed):
     from dxrs_amd import textures as T
     rng = np.random.default_rng(9100 + seed)
@@ -157,12 +236,16 @@ def test_gpu_environment_map_matches_oracle(dxrs, host, oracle, renderer, seed):
     spheres, materials, ts = make_textured_scene(dxrs, rng, n, seed % 2)
     if seed % 3 == 0:  # the environment map alone: no sphere has maps
         ts = T.TextureSet(n)
-    if seed % 2:
+    cube = seed % 5 in (1, 4)
+    if cube:
+        size = int(rng.integers(1, 9))
+        idx = ts.add_cube([rng.uniform(0, 4, (size, size, 4)).astype(np.float32) for _ in range(6)])
+    elif seed % 2:
         idx = ts.add_hdr_image(T.sky_latlong(128, 64, seed=seed))
     else:
         idx = ts.add_hdr_image(rng.uniform(0, 4, (int(rng.integers(1, 9)), int(rng.integers(1, 17)), 4)).astype(np.float32))
     matrix = [None, random_rotation(rng), rng.normal(size=(3, 3))][seed % 3]  # incl. a non-orthonormal transform (normalised after)
-    sd = set_env(host.scene(dxrs.host.SCENE_SMALL)[2], idx, matrix)
+    sd = (set_cube if cube else set_env)(host.scene(dxrs.host.SCENE_SMALL)[2], idx, matrix)
     w, h = int(rng.choice([64, 97])), int(rng.choice([48, 61]))
     pos = (0.0, 0.5, -12.0) if seed % 3 else (0.2, 0.1, 0.0)
     cam = host.camera(w, h, position=pos, jitter_index=seed)
@@ -186,10 +269,17 @@ def test_gpu_environment_map_api(dxrs, host, oracle, renderer):
     w, h = 128, 96
     cam, gs = host.camera(w, h), t.graphics_settings(w, h, bounces=3)
     renderer.set_camera(cam); renderer.set_constants(gs)
-    # cube maps are refused at pt_set_scene
-    cube = set_env(sd, 0); cube.IsEnvironmentLightTextureCubeMap = 1
-    with pytest.raises(RuntimeError, match="cube"):
-        renderer.set_scene(spheres, materials, cube)
+    # a cube map needs six square table entries of one size
+    ts6 = T.TextureSet(n)
+    ts6.add_cube([np.ones((2, 2, 3), np.float32)] * 5 + [np.ones((2, 3, 3), np.float32)])
+    renderer.set_scene(spheres, materials, set_cube(sd, 0))
+    renderer.set_textures(ts6)
+    with pytest.raises(RuntimeError, match="square"):
+        renderer.render()
+    renderer.set_scene(spheres, materials, set_cube(sd, 1))
+    renderer.set_textures(ts6)
+    with pytest.raises(RuntimeError, match="six consecutive"):
+        renderer.render()
     # a descriptor without a table fails at render time, loudly
     env_sd = set_env(sd, 0, rot_y(0.7))
     renderer.set_scene(spheres, materials, env_sd)
