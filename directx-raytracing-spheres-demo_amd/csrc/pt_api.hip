@@ -50,6 +50,7 @@ struct Lane {
     uint32_t* h_prev_counts = nullptr;   // host-mapped: the GPU writes it when it folds a frame's counters (no copy call)
     uint32_t* d_prev_counts = nullptr;   // device address of h_prev_counts
     uint64_t prev_signature = 0;
+    uint32_t* d_seg_counts = nullptr;        // kMaxSegs segment sizes of the primary pass -> looping pass hand-over
     unsigned long long* d_totals = nullptr;  // [0] running secondary-ray total, [1] last folded frame, [2],[3] tail counters,
                                              // [4] running count of in-register secondary rays of primary passes, [5] unused
     // private copy of the moving part of the scene (pt_update_spheres / pt_refit_accel): spheres, Morton-ordered spheres
@@ -376,7 +377,20 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         PT_HIP(c, hipStreamSynchronize(L.stream));
     }
     const bool di = c->gs.IsDIEnabled && c->n_lights > 0;
-    PtStatus st = ensure_buffers(c, L, pm.n_slots, spp > 1, split, wf_cap + 2, di);
+    // Persistent workgroups: with the BVH staged into LDS per workgroup, 2 per CU (= the 4 waves/SIMD the kernel is built
+    // for) amortise the 37 KB staging over ~4 batches of rays at 1080p / 1 spp (0.121 -> 0.116 ms per frame); with spp > 1
+    // the passes are long and uneven, and more, shorter workgroups balance better (C3: 6.77 vs 6.89 ms).
+    // (... from about 1.5 M slots: below that 8 per CU is 4-10 % faster)
+    const uint32_t trav_cap = c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", spp == 1 && c->lds_scene && pm.n_slots >= 1500000u ? 2 : 8);
+    const uint32_t fused_threads = c->lds_scene ? env_u32("PT_FUSED_THREADS", 512) : 256u;
+    auto grid_for = [](uint32_t items, uint32_t threads, uint32_t cap) { return std::max(1u, std::min((items + threads - 1) / threads, cap)); };
+    // Segmented hand-over from the primary pass to the looping pass (FrameCounters::seg_counts): workgroup b owns the queue
+    // entries [b * seg_cap, (b + 1) * seg_cap), seg_cap = the slots it visits -- the queues get that much room
+    const uint32_t primary_grid = grid_for(pm.n_slots, fused_threads, trav_cap);
+    const uint32_t primary_batches = (pm.n_slots + fused_threads - 1) / fused_threads;
+    const uint32_t seg_cap = (primary_batches + primary_grid - 1) / primary_grid * fused_threads;
+    const size_t seg_total = (size_t)primary_grid * seg_cap;
+    PtStatus st = ensure_buffers(c, L, split ? pm.n_slots : std::max<size_t>(pm.n_slots, seg_total), spp > 1, split, wf_cap + 2, di);
     if (st != PT_OK) return st;
     if (L.stream != c->stream) {
         // N frames in flight.  The caller rotates over N output buffers, so this frame may start as soon as the consumer of
@@ -412,11 +426,6 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         const uint64_t e = (uint64_t)L.h_prev_counts[k] + L.h_prev_counts[k] / 4 + 64;
         return (uint32_t)std::min<uint64_t>(e, pm.n_slots);
     };
-    // Persistent workgroups: with the BVH staged into LDS per workgroup, 2 per CU (= the 4 waves/SIMD the kernel is built
-    // for) amortise the 37 KB staging over ~4 batches of rays at 1080p / 1 spp (0.121 -> 0.116 ms per frame); with spp > 1
-    // the passes are long and uneven, and more, shorter workgroups balance better (C3: 6.77 vs 6.89 ms).
-    // (... from about 1.5 M slots: below that 8 per CU is 4-10 % faster)
-    const uint32_t trav_cap = c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", spp == 1 && c->lds_scene && pm.n_slots >= 1500000u ? 2 : 8);
     const uint32_t trav_cap_wide = c->num_cus * 8u;
     const uint32_t shade_cap = c->num_cus * env_u32("PT_SHADE_BLOCKS_PER_CU", 16);
     // the looping pass: small queues at 1 spp (256 threads, up to 8 workgroups per CU); at spp > 1 of the fused schedule it
@@ -424,9 +433,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     // persistent 512-thread workgroups per CU (C3: 6.7 -> 4.8 ms per frame against 33 queue passes + a small looping pass)
     const bool loop_is_main = spp > 1 && !split && !std::getenv("PT_TAIL_THRESHOLD");
     const uint32_t tail_cap = c->num_cus * env_u32("PT_TAIL_BLOCKS_PER_CU", loop_is_main ? 2 : 8);
-    auto grid_for = [](uint32_t items, uint32_t threads, uint32_t cap) { return std::max(1u, std::min((items + threads - 1) / threads, cap)); };
     const uint32_t trav_threads = traverse_threads(c->lds_scene);
-    const uint32_t fused_threads = c->lds_scene ? env_u32("PT_FUSED_THREADS", 512) : 256u;
     const uint32_t loop_threads = env_u32("PT_LOOP_THREADS", loop_is_main && c->lds_scene ? 512u : 256u);
     // Queue-fed passes before the looping kernel (spp == 1).  Fused, large frames: the primary pass also traces the first bounce
     // in registers (bounce_kernel kInline2) and the looping kernel follows it directly -- two launches per frame: 4-10 % faster at
@@ -478,6 +485,12 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         PT_HIP(c, bracket(1, [&] { return launch_di(sv, pm, fp, L.scratch.di, fc.tail_rays, di_grid, L.stream); }));
     }
     if (!split) {
+        // The looping pass follows the primary pass directly (1 spp with the in-register second bounce; spp > 1): the hand-over
+        // is segmented -- no barrier, no global atomic per batch in the primary pass (PT_SEG=0: the dense queue, for A/B runs).
+        const bool loop_follows_primary = loop_is_main || (spp == 1 && (tail_after == 0 || wf_cap <= 2));
+        const bool seg = loop_follows_primary && max_iters > 1 && primary_grid <= kMaxSegs && seg_total <= L.cap_slots && env_u32("PT_SEG", 1u) != 0 && !std::getenv("PT_LOOP_USE_TAIL");
+        FrameCounters fc_seg = fc;
+        if (seg) { fc_seg.seg_counts = L.d_seg_counts; fc_seg.n_segs = primary_grid; fc_seg.seg_cap = seg_cap; }
         // pass 0 generates + traces the primaries and shades them into queue 1; pass k >= 1 consumes queue k
         for (size_t k = 0;; k++) {
             const RayQueue& qin = L.q[k & 1];
@@ -499,8 +512,8 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
                 break;
             }
             PT_HIP(c, bracket(loop ? 3 : (primary ? 0 : 1), [&] {
-                return launch_bounce(sv, pm, fp, qin, qout, L.scratch, out, counts + k, counts + k + 1, fc, primary, loop, inline2, threads,
-                                     grid_for(items, threads, cap), L.stream);
+                return launch_bounce(sv, pm, fp, qin, qout, L.scratch, out, counts + k, counts + k + 1, k <= 1 ? fc_seg : fc, primary, loop, inline2, threads,
+                                     primary ? primary_grid : grid_for(items, threads, cap), L.stream);
             }));
             if (loop || last_possible) break;
         }
@@ -641,6 +654,7 @@ PtStatus pt_create(const PtConfig* config, PtContext** out_ctx)
         for (auto& e : L.ev_poll) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         if (!ok || hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) != hipSuccess
             || hipMalloc(&L.d_totals, 6 * sizeof(unsigned long long)) != hipSuccess
+            || hipMalloc(&L.d_seg_counts, kMaxSegs * sizeof(uint32_t)) != hipSuccess
             || hipMemsetAsync(L.d_totals, 0, 6 * sizeof(unsigned long long), L.stream) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
     }
     *out_ctx = c;
@@ -658,7 +672,7 @@ void pt_destroy(PtContext* c)
         free_lane_scene(L);
         if (L.ev_upload) (void)hipEventDestroy(L.ev_upload);
         for (auto& e : L.ev_poll) if (e) (void)hipEventDestroy(e);
-        free_dev(L.d_counts); free_dev(L.d_totals);
+        free_dev(L.d_counts); free_dev(L.d_totals); free_dev(L.d_seg_counts);
         if (L.h_counts) (void)hipHostFree(L.h_counts);
         if (L.h_prev_counts) (void)hipHostFree(L.h_prev_counts);
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);
@@ -1048,7 +1062,7 @@ PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_tex
     for (uint32_t i = 0; i < n; i++) {
         uint32_t any = 0;
         for (uint32_t k = 0; k < PT_TEXTURE_MAP_COUNT; k++) {
-            const PtTextureMapInfo none{~0u, 0u, 0u, 0u};
+            const PtTextureMapInfo none{ ~0u, 0u, { 0u, 0u } };
             const PtTextureMapInfo& mi = object_textures ? object_textures[i].Maps[k] : none;
             if (mi.Descriptor != ~0u) {
                 if (mi.Descriptor >= n_textures) return fail(c, PT_ERR_INVALID_ARG, "pt_set_textures: Descriptor out of range");

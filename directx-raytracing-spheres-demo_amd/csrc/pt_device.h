@@ -151,7 +151,16 @@ struct FrameCounters {
     unsigned long long* totals;
     uint32_t* host_counts;  // host-mapped (pinned) copy of the queue sizes of the frame being folded: launch-grid estimates
                             // for later frames reach the host without a copy call; may be null
+    // Segmented hand-over from the primary pass to the looping pass (null = dense queue): workgroup b of the primary pass
+    // appends its surviving rays to its own segment [b * seg_cap, ...) of the queue, through a counter in LDS -- no barrier
+    // and no global atomic per batch -- and leaves the segment's size in seg_counts[b]; the looping pass maps a dense index
+    // to (segment, offset) through a prefix sum it builds in LDS.
+    uint32_t* seg_counts;
+    uint32_t n_segs;        // == grid size of the primary pass, <= kMaxSegs
+    uint32_t seg_cap;       // entries per segment
 };
+
+constexpr uint32_t kMaxSegs = 2048;
 
 // per-slot scratch (only touched when needed, see shade kernel)
 struct Scratch {

@@ -672,9 +672,42 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
     extern __shared__ float4 smem[];
     __shared__ uint32_t s_wave_count[kFusedThreads / 64];
     __shared__ uint32_t s_block_base;
+    __shared__ uint32_t s_seg_count;                  // producer side of the segmented hand-over (FrameCounters::seg_counts)
+    __shared__ uint32_t s_seg_prefix[kMaxSegs + 1];   // consumer side: s_seg_prefix[b] = entries in segments < b
     if (kPrimary && blockIdx.x == 0) frame_counters_begin(fc, pm.n_slots);
-    const uint32_t count = kPrimary ? pm.n_slots : *count_in_ptr;
-    if (blockIdx.x * blockDim.x >= count) return;
+    const bool seg_out = kPrimary && !kLoop && fc.seg_counts != nullptr;
+    const bool seg_in = !kPrimary && kLoop && fc.seg_counts != nullptr;
+    uint32_t count;
+    if (seg_in) {
+        // exclusive prefix sum of the segment sizes: thread t sums a run of consecutive segments, the runs are scanned per wave
+        // (shuffles) and across waves (s_wave_count), then every thread writes the prefixes of its run
+        const uint32_t per = (fc.n_segs + blockDim.x - 1u) / blockDim.x;
+        const uint32_t first = threadIdx.x * per;
+        uint32_t sum = 0;
+        for (uint32_t j = 0; j < per; j++) if (first + j < fc.n_segs) sum += fc.seg_counts[first + j];
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if ((int)lane_id() >= off) incl += v; }
+        if (lane_id() == 63u) s_wave_count[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t base = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += s_wave_count[w];
+        uint32_t run = base + incl - sum;
+        for (uint32_t j = 0; j < per; j++)
+            if (first + j < fc.n_segs) { s_seg_prefix[first + j] = run; run += fc.seg_counts[first + j]; }
+        if (threadIdx.x == blockDim.x - 1u) s_seg_prefix[fc.n_segs] = base + incl;
+        __syncthreads();
+        count = s_seg_prefix[fc.n_segs];
+        if (blockIdx.x == 0 && threadIdx.x == 0) *const_cast<uint32_t*>(count_in_ptr) = count;  // the queue size, for the statistics and the next frame's grid estimate
+    } else {
+        count = kPrimary ? pm.n_slots : *count_in_ptr;
+    }
+    if (seg_out && threadIdx.x == 0) s_seg_count = 0;
+    if (blockIdx.x * blockDim.x >= count) {
+        if (seg_out && threadIdx.x == 0) fc.seg_counts[blockIdx.x] = 0;
+        return;
+    }
+    if (seg_out && !kLds) __syncthreads();  // (with kLds the barrier of stage_scene orders the reset)
     const float4* nodes = sv.nodes;
     const float4* sph = sv.sph_sorted;
     const uint32_t* ids = sv.sorted_id;
@@ -692,8 +725,23 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t my_rays = 0;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
-        const uint32_t i = base + threadIdx.x;
+    // Work distribution: a static grid-stride over the batches -- except for the looping pass behind a segmented hand-over,
+    // where every WAVE pulls its next 64 entries from a work cursor (one atomic per 64 paths; no barrier inside this loop in
+    // the looping form): a segment lists one workgroup's tiles top to bottom of the image, and a static stride over such a
+    // queue can hand a workgroup the same image region again and again (C3: 7.2 vs 6.5 ms for the looping pass).
+    uint32_t* const cursor = const_cast<uint32_t*>(count_in_ptr) + fc.n_counts + 1u;  // the work cursor of this queue (zeroed when the counters are folded)
+    for (uint32_t base = blockIdx.x * blockDim.x;; base += gridDim.x * blockDim.x) {
+        uint32_t i;
+        if (seg_in) {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(cursor, 64u);
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (b >= count) break;
+            i = b + lane;
+        } else {
+            if (base >= count) break;
+            i = base + threadIdx.x;
+        }
         bool emit = false;
         PathState ps;
         if (i < count) {
@@ -711,6 +759,11 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
                 } else if (pm.mode == 1) {
                     out[pr.out_index] = make_float4(0.f, 0.f, 0.f, 0.f);  // padding pixel of an edge tile
                 }
+            } else if (seg_in) {
+                // dense index -> (segment, offset): the last segment whose prefix is <= i
+                uint32_t lo = 0, hi = fc.n_segs;
+                while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_seg_prefix[mid] <= i) lo = mid; else hi = mid; }
+                ps = load_path(qin, lo * fc.seg_cap + (i - s_seg_prefix[lo]));
             } else {
                 ps = load_path(qin, i);
             }
@@ -731,7 +784,17 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
                 }
             }
         }
-        if (!kLoop) {
+        if (seg_out) {
+            // Segmented hand-over: the wave reserves room in the workgroup's own segment with ONE LDS atomic; no barrier -- the
+            // waves of a workgroup no longer wait for its slowest wave after every batch (the barriers of the dense form below
+            // cost 18 % of the primary pass at C2: 132 -> 109 us measured with the compaction compiled out).
+            const unsigned long long mask = __ballot(emit);
+            const uint32_t wave_n = __popcll(mask);
+            uint32_t base = 0;
+            if (lane == 0 && wave_n) base = atomicAdd(&s_seg_count, wave_n);
+            base = __shfl(base, 0, 64);
+            if (emit) store_path(qout, blockIdx.x * fc.seg_cap + base + __popcll(mask & ((1ull << lane) - 1ull)), ps);
+        } else if (!kLoop) {
             // One atomic per WORKGROUP.  (One per wave -- no barriers, waves never wait for each other -- was measured and is
             // far worse: 0.116 -> 0.201 ms per C2 frame; 8x as many same-address device-scope atomics from 8 XCDs serialise.)
             const unsigned long long mask = __ballot(emit);
@@ -749,6 +812,10 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
             if (emit) store_path(qout, s_block_base + s_wave_count[wave] + prefix, ps);
             __syncthreads();
         }
+    }
+    if (seg_out) {
+        __syncthreads();
+        if (threadIdx.x == 0) fc.seg_counts[blockIdx.x] = s_seg_count;
     }
     if (kLoop || kIters > 1u) {
         // rays traced in registers: wave reduce, then ONE atomic pair per workgroup (same-address device-scope atomics from
