@@ -673,6 +673,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
     __shared__ uint32_t s_wave_count[kFusedThreads / 64];
     __shared__ uint32_t s_block_base;
     __shared__ uint32_t s_seg_count;                  // producer side of the segmented hand-over (FrameCounters::seg_counts)
+    __shared__ uint32_t s_seg_next;                   // ... and the next 64-slot tile of this workgroup's batches to hand to a wave
     __shared__ uint32_t s_seg_prefix[kMaxSegs + 1];   // consumer side: s_seg_prefix[b] = entries in segments < b
     if (kPrimary && blockIdx.x == 0) frame_counters_begin(fc, pm.n_slots);
     const bool seg_out = kPrimary && !kLoop && fc.seg_counts != nullptr;
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
     } else {
         count = kPrimary ? pm.n_slots : *count_in_ptr;
     }
-    if (seg_out && threadIdx.x == 0) s_seg_count = 0;
+    if (seg_out && threadIdx.x == 0) { s_seg_count = 0; s_seg_next = 0; }
     if (blockIdx.x * blockDim.x >= count) {
         if (seg_out && threadIdx.x == 0) fc.seg_counts[blockIdx.x] = 0;
         return;
@@ -738,6 +739,16 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
             b = __builtin_amdgcn_readfirstlane(b);
             if (b >= count) break;
             i = b + lane;
+        } else if (seg_out) {
+            // the workgroup's batches are the same strided set as below, but its waves take the 64-slot tiles of them from a
+            // counter in LDS: a wave that drew sky tiles moves on instead of idling behind its neighbours
+            uint32_t w = 0;
+            if (lane == 0) w = atomicAdd(&s_seg_next, 1u);
+            w = __builtin_amdgcn_readfirstlane(w);
+            const uint32_t waves = blockDim.x >> 6;
+            const uint32_t b = (blockIdx.x + (w / waves) * gridDim.x) * blockDim.x;
+            if (b >= count) break;
+            i = b + (w % waves) * 64u + lane;
         } else {
             if (base >= count) break;
             i = base + threadIdx.x;
