@@ -378,10 +378,11 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     }
     const bool di = c->gs.IsDIEnabled && c->n_lights > 0;
     // Persistent workgroups: with the BVH staged into LDS per workgroup, 2 per CU (= the 4 waves/SIMD the kernel is built
-    // for) amortise the 37 KB staging over ~4 batches of rays at 1080p / 1 spp (0.121 -> 0.116 ms per frame); with spp > 1
-    // the passes are long and uneven, and more, shorter workgroups balance better (C3: 6.77 vs 6.89 ms).
-    // (... from about 1.5 M slots: below that 8 per CU is 4-10 % faster)
-    const uint32_t trav_cap = c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", spp == 1 && c->lds_scene && pm.n_slots >= 1500000u ? 2 : 8);
+    // for) amortise the 37 KB staging over ~4 batches of rays at 1080p / 1 spp (0.121 -> 0.116 ms per frame), from about
+    // 1.5 M slots: below that 8 per CU is 4-10 % faster.  (Since the waves of a workgroup draw their tiles dynamically the
+    // same holds at spp > 1 -- C3: 3.61 ms with 2 per CU, 3.68 with 8.)
+    const bool big_frame = c->lds_scene && pm.n_slots >= 1500000u;
+    const uint32_t trav_cap = c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", big_frame ? 2 : 8);
     const uint32_t fused_threads = c->lds_scene ? env_u32("PT_FUSED_THREADS", 512) : 256u;
     auto grid_for = [](uint32_t items, uint32_t threads, uint32_t cap) { return std::max(1u, std::min((items + threads - 1) / threads, cap)); };
     // Segmented hand-over from the primary pass to the looping pass (FrameCounters::seg_counts): workgroup b owns the queue
@@ -434,7 +435,9 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     const bool loop_is_main = spp > 1 && !split && !std::getenv("PT_TAIL_THRESHOLD");
     const uint32_t tail_cap = c->num_cus * env_u32("PT_TAIL_BLOCKS_PER_CU", loop_is_main ? 2 : 8);
     const uint32_t trav_threads = traverse_threads(c->lds_scene);
-    const uint32_t loop_threads = env_u32("PT_LOOP_THREADS", loop_is_main && c->lds_scene ? 512u : 256u);
+    // looping pass: 512-thread workgroups when it carries the frame (spp > 1) and, at 1 spp, for big frames (1080p: 0.0954 ->
+    // 0.0887 ms, 4K: 0.329 -> 0.302; at 960x540 and below 256 threads are 6-7 % faster)
+    const uint32_t loop_threads = env_u32("PT_LOOP_THREADS", c->lds_scene && (loop_is_main || big_frame) ? 512u : 256u);
     // Queue-fed passes before the looping kernel (spp == 1).  Fused, large frames: the primary pass also traces the first bounce
     // in registers (bounce_kernel kInline2) and the looping kernel follows it directly -- two launches per frame: 4-10 % faster at
     // every frame size from 256x256 to 4K (PT_INLINE2_MIN_SLOTS switches it off below a slot count, for A/B runs).
