@@ -186,9 +186,9 @@ PtStatus ensure_buffers(PtContext* c, Lane& L, size_t n_slots, bool need_spp, bo
         L.cap_slots = n_slots;
     }
     if (need_di && !L.scratch.di) PT_HIP(c, hipMalloc(&L.scratch.di, L.cap_slots * sizeof(float4)));
+    if ((need_spp || need_di) && !L.scratch.primary_hit) PT_HIP(c, hipMalloc(&L.scratch.primary_hit, L.cap_slots * sizeof(uint2)));
     if (need_spp && !L.scratch_spp) {
         PT_HIP(c, hipMalloc(&L.scratch.radiance, L.cap_slots * sizeof(float4)));
-        PT_HIP(c, hipMalloc(&L.scratch.primary_hit, L.cap_slots * sizeof(uint2)));
         L.scratch_spp = true;
     }
     if (n_counts > L.cap_counts) {
@@ -485,7 +485,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     if (fp.di_enabled) {
         // row N4: the direct-illumination estimate of every primary surface, before the bounce passes read it
         const uint32_t di_grid = grid_for(pm.n_slots, trav_threads, trav_cap_wide);
-        PT_HIP(c, bracket(1, [&] { return launch_di(sv, pm, fp, L.scratch.di, fc.tail_rays, di_grid, L.stream); }));
+        PT_HIP(c, bracket(1, [&] { return launch_di(sv, pm, fp, L.scratch.di, L.scratch.primary_hit, fc.tail_rays, di_grid, L.stream); }));
     }
     if (!split) {
         // The looping pass follows the primary pass directly (1 spp with the in-register second bounce; spp > 1): the hand-over

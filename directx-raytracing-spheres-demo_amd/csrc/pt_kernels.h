@@ -36,7 +36,7 @@ hipError_t launch_unpack_tiles(const float4* packed, float4* frame, uint32_t w, 
                                uint32_t run, uint32_t stride, uint32_t n_parts, uint64_t part_stride, bool rgb, hipStream_t stream);
 hipError_t launch_pack_rgb(const float4* src, float* dst, uint64_t n, hipStream_t stream);
 
-hipError_t launch_di(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, float4* di, unsigned long long* ray_counter, uint32_t grid,
+hipError_t launch_di(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, float4* di, uint2* primary_hit, unsigned long long* ray_counter, uint32_t grid,
                      hipStream_t stream);
 hipError_t launch_tonemap(const float4* hdr, uint32_t* out, uint32_t n, const PtToneMapParams& p, hipStream_t stream);
 hipError_t launch_accumulate(float4* accum, const float4* rad, uint32_t n, uint32_t frames_accumulated, hipStream_t stream);

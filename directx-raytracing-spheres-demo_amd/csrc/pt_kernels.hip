@@ -784,8 +784,13 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
                 for (;;) {
                     float t;
                     uint32_t id;
-                    closest_hit<StackT>(nodes, sph, ids, sv.n, ps.o, ps.d, tmin, tmax, stack, blockDim.x, t, id);
-                    if (kMulti && kPrimary && primary_trace) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
+                    if (kPrimary && primary_trace && fp.di_enabled) {
+                        const uint2 ph = scratch.primary_hit[i];  // traced by the direct-illumination pass (row N4)
+                        t = as_float(ph.x); id = ph.y;
+                    } else {
+                        closest_hit<StackT>(nodes, sph, ids, sv.n, ps.o, ps.d, tmin, tmax, stack, blockDim.x, t, id);
+                        if (kMulti && kPrimary && primary_trace) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
+                    }
                     primary_trace = false;
                     emit = shade_step<kMulti, kTex>(sv, pm, fp, scratch, out, ps, t, id);
                     if (!emit) break;
@@ -855,7 +860,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
 // the first thing it meets -- and store  DI = Le * (f_diffuse + f_specular) cos * n_lights / pdf.
 // shade_step drops the emission of first-bounce hits reached through a reflective lobe and adds DI to the final radiance.  Own RNG stream; both rays are counted.
 template <bool kLds, typename StackT, bool kTex>
-__global__ __launch_bounds__(kTraverseThreads) void di_kernel(SceneView sv, PixelMap pm, FrameParams fp, float4* __restrict__ di,
+__global__ __launch_bounds__(kTraverseThreads) void di_kernel(SceneView sv, PixelMap pm, FrameParams fp, float4* __restrict__ di, uint2* __restrict__ primary_hit,
                                                               unsigned long long* __restrict__ ray_counter)
 {
     extern __shared__ float4 smem[];
@@ -883,7 +888,9 @@ __global__ __launch_bounds__(kTraverseThreads) void di_kernel(SceneView sv, Pixe
             uint32_t id;
             primary_ray(fp.cam, pr.px, pr.py, o, d, tmin, tmax);
             closest_hit<StackT>(nodes, sph, ids, sv.n, o, d, tmin, tmax, stack, blockDim.x, t, id);
-            my_rays++;
+            // THE primary trace of this frame: the primary pass that follows reads the hit instead of tracing again (as the
+            // reference's RTXDI passes and Raytracing.hlsl both start from the G-buffer); it is counted there (queue 0)
+            primary_hit[slot] = make_uint2(as_uint(t), id);
             if (id != kMissId) {
                 const HitMaterial hm = hit_material<kTex>(sv, id, o, d, t, true);
                 uint32_t rng = rng_init(pr.px, pr.py, fp.frame_index ^ kDiRngSalt);
@@ -1184,7 +1191,7 @@ hipError_t launch_unpack_tiles(const float4* packed, float4* frame, uint32_t w, 
     return hipGetLastError();
 }
 
-hipError_t launch_di(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, float4* di, unsigned long long* ray_counter, uint32_t grid,
+hipError_t launch_di(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, float4* di, uint2* primary_hit, unsigned long long* ray_counter, uint32_t grid,
                      hipStream_t stream)
 {
     const bool small = sv.n_nodes < 32767u;
@@ -1193,7 +1200,7 @@ hipError_t launch_di(const SceneView& sv, const PixelMap& pm, const FrameParams&
 #define PT_DI2(L, T, X)                                                                                                     \
     do {                                                                                                                    \
         if (lds > 65536u) (void)hipFuncSetAttribute((const void*)di_kernel<L, T, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((di_kernel<L, T, X>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, di, ray_counter);       \
+        hipLaunchKernelGGL((di_kernel<L, T, X>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, di, primary_hit, ray_counter);       \
     } while (0)
 #define PT_DI(L, T) do { if (sv.tex_maps) PT_DI2(L, T, true); else PT_DI2(L, T, false); } while (0)
     if (sv.lds_scene) { if (small) PT_DI(true, uint16_t); else PT_DI(true, uint32_t); }

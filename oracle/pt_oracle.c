@@ -1104,7 +1104,6 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
     cast_ray(accel, sph, n, o, d, tmin, tmax, &primary);
     rays++;
     const int di_on = gs->IsDIEnabled && lights && lights->n > 0;
-    if (di_on) rays++; /* the DI pass traces the primary ray again */
     if (!primary.hit) { /* miss: Radiance = env (GBufferGeneration.hlsl:223-227); bounce loop returns without writing (:249-252) */
         v3 c = environment_color(tc, sd, d);
         rgba[0] = c.x; rgba[1] = c.y; rgba[2] = c.z; rgba[3] = 1.0f;
