@@ -415,7 +415,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     L.parity ^= 1u;
     const FrameCounters fc = make_counters(L, L.parity);
     uint32_t* counts = fc.counts;
-    if (traverse_lds_bytes_for(sv.n_nodes, sv.n, sv.stack_depth, c->lds_scene) > kMaxLdsBytes)
+    if (traverse_lds_bytes_for(sv.n_nodes, sv.n, sv.stack_depth, c->lds_scene) > kMaxLdsBytes - 9u * 1024u)  // (the kernels' static LDS comes on top)
         return fail(c, PT_ERR_UNSUPPORTED, "BVH depth needs more traversal-stack LDS than a workgroup can have");
 
     // Launch grids: a kernel's queue size lives on the device; the host sizes the grid from the queue sizes an

@@ -648,6 +648,10 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(SceneView sv, PixelM
     block_atomic_add(tail_rays, my_rays);
 }
 
+// static LDS of the kernels below (counters, the segment prefix table of the looping pass) on top of their dynamic LDS: the
+// 64 KB default limit counts both, so the opt-in for more is taken this much earlier
+constexpr uint32_t kStaticLdsMargin = (kMaxSegs + 64u) * 4u;
+
 // ------------------------------------------------------------------------------------------------ fused bounce
 // trace + shade in one kernel (DESIGN.md "Kernels"): a lane obtains a ray (kPrimary: generated from its pixel; else read
 // from the input queue), traces it, and runs one shade_step.  kLoop = false: survivors are compacted into the output
@@ -1062,7 +1066,7 @@ uint32_t traverse_lds_bytes_for(uint32_t n_nodes, uint32_t n, uint32_t depth, bo
     do {                                                                                                        \
         const bool small = sv.n_nodes < 32767u;                                                                 \
         const uint32_t lds = traverse_lds_bytes(sv, small ? 2u : 4u);                                           \
-        if (lds > 65536u) {                                                                                     \
+        if (lds + kStaticLdsMargin > 65536u) {                                                                                     \
             const void* fn = sv.lds_scene ? (small ? (const void*)KERNEL<true, uint16_t> : (const void*)KERNEL<true, uint32_t>)   \
                                           : (small ? (const void*)KERNEL<false, uint16_t> : (const void*)KERNEL<false, uint32_t>); \
             (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
@@ -1106,7 +1110,7 @@ hipError_t launch_tail(const SceneView& sv, const PixelMap& pm, const FrameParam
     const uint32_t lds = (sv.lds_scene ? scene_lds_bytes(sv.n_nodes, sv.n) : 0u) + kTailThreads * sv.stack_depth * elem;
 #define PT_TAIL2(L, T, X)                                                                                                  \
     do {                                                                                                                    \
-        if (lds > 65536u) (void)hipFuncSetAttribute((const void*)tail_kernel<L, T, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds + kStaticLdsMargin > 65536u) (void)hipFuncSetAttribute((const void*)tail_kernel<L, T, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((tail_kernel<L, T, X>), dim3(grid), dim3(kTailThreads), lds, stream, sv, pm, fp, qin, scratch, out, count_ptr, tail_rays); \
     } while (0)
 #define PT_TAIL(L, T) do { if (sv.tex_maps) PT_TAIL2(L, T, true); else PT_TAIL2(L, T, false); } while (0)
@@ -1126,7 +1130,7 @@ hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FramePar
     const uint32_t lds = (sv.lds_scene ? scene_lds_bytes(sv.n_nodes, sv.n) : 0u) + threads * sv.stack_depth * elem;
 #define PT_BOUNCE6(L, T, P, LP, M, X, I)                                                                                   \
     do {                                                                                                                    \
-        if (lds > 65536u) (void)hipFuncSetAttribute((const void*)bounce_kernel<L, T, P, LP, M, X, I>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds + kStaticLdsMargin > 65536u) (void)hipFuncSetAttribute((const void*)bounce_kernel<L, T, P, LP, M, X, I>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((bounce_kernel<L, T, P, LP, M, X, I>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out, fc); \
     } while (0)
 /* the in-register second bounce exists only for the 1-spp compacting primary pass */
@@ -1199,7 +1203,7 @@ hipError_t launch_di(const SceneView& sv, const PixelMap& pm, const FrameParams&
     const uint32_t lds = traverse_lds_bytes(sv, small ? 2u : 4u);
 #define PT_DI2(L, T, X)                                                                                                     \
     do {                                                                                                                    \
-        if (lds > 65536u) (void)hipFuncSetAttribute((const void*)di_kernel<L, T, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds + kStaticLdsMargin > 65536u) (void)hipFuncSetAttribute((const void*)di_kernel<L, T, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((di_kernel<L, T, X>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, di, primary_hit, ray_counter);       \
     } while (0)
 #define PT_DI(L, T) do { if (sv.tex_maps) PT_DI2(L, T, true); else PT_DI2(L, T, false); } while (0)

@@ -85,3 +85,23 @@ def test_random_large_scene_matches_oracle(dxrs, host, oracle, renderer, seed):
     ref, ost = oracle.render(spheres, materials, sd, cam, gs, threads=8)
     assert st.rays == ost.rays
     assert count_mismatch(img, ref) == 0
+
+
+# sphere counts around the limits of the LDS-resident path: the scene copy (84 B per sphere) plus the per-lane stacks cross the
+# 64 KB default LDS limit of a workgroup (static + dynamic) near 600-700 spheres and the residency budget shortly after
+@pytest.mark.parametrize("n", [520, 560, 600, 620, 640, 660, 680, 700, 740, 780, 820])
+def test_scene_sizes_around_the_lds_limits(dxrs, host, oracle, renderer, n):
+    rng = np.random.default_rng(9000 + n)
+    spheres, materials = random_scene(dxrs, rng, n)
+    sd = host.scene(dxrs.host.SCENE_SMALL)[2]
+    w, h = 96, 64
+    cam = host.camera(w, h, position=(0.3, 0.2, -12.0), jitter_index=n)
+    renderer.set_scene(spheres, materials, sd)
+    renderer.set_camera(cam)
+    for spp, bounces in ((1, 5), (3, 2)):
+        gs = dxrs.types.graphics_settings(w, h, frame_index=n, bounces=bounces, spp=spp)
+        renderer.set_constants(gs)
+        img, st = renderer.render()
+        ref, ost = oracle.render(spheres, materials, sd, cam, gs, threads=8)
+        assert st.rays == ost.rays
+        assert count_mismatch(img, ref) == 0
