@@ -56,6 +56,12 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="the CPU baseline renders every n-th row of each frame")
     args = ap.parse_args()
+    # stdout carries exactly one line, the result.  Libraries print there too (RCCL announces its version on stdout when the
+    # communicator comes up), so file descriptor 1 is pointed at stderr for the run and the result goes to the saved original.
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -362,7 +368,7 @@ def main():
         }
 
     if rank == 0:
-        print(json.dumps(result))
+        os.write(_RESULT_FD, (json.dumps(result) + "\n").encode())  # the ONE line of this job's stdout
     r.close()
     if tiled:
         dist.destroy_process_group()
