@@ -63,6 +63,7 @@ def main():
     _RESULT_FD = os.dup(1)
     os.dup2(2, 1)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on these hosts (normally already exported)
     import torch
     import torch.distributed as dist
 
