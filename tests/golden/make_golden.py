@@ -30,18 +30,15 @@ def main():
     halton = np.array([[lib.oracle_halton(i, b) for b in (2, 3, 5)] for i in range(1, 65)], dtype=np.float32)
     np.save(os.path.join(HERE, "halton_1_64.npy"), halton)
 
-    # config C1 (16 spheres, 256x256, 1 spp, 4 bounces, frame 0): 64x64 crop around the hero spheres
+    sys.path.insert(0, os.path.dirname(HERE))
+    import golden_cases
+    for c in golden_cases.cases(dxrs_amd, host):
+        img, _ = oracle.render(c["spheres"], c["materials"], c["sd"], c["cam"], c["gs"], rect=c["rect"], threads=8, textures=c["textures"])
+        np.save(os.path.join(HERE, c["file"]), img)
+    src, dst, params = golden_cases.tonemap_case(dxrs_amd)
+    np.save(os.path.join(HERE, dst), oracle.tonemap(np.load(os.path.join(HERE, src)), params))
     spheres, materials, sd = host.scene(dxrs_amd.host.SCENE_SMALL, seed=0)
-    gs = dxrs_amd.types.graphics_settings(256, 256, frame_index=0, bounces=4, spp=1)
-    cam = host.camera(256, 256, jitter_index=0)
-    img, stats = oracle.render(spheres, materials, sd, cam, gs, rect=(96, 80, 64, 64), threads=4)
-    np.save(os.path.join(HERE, "c1_crop_96_80_64x64.npy"), img)
-    # config C2 (demo scene seed 0, 1920x1080, 1 spp, 8 bounces, frame 0): 64x32 crop over the glass / bronze heroes
     spheres2, materials2, sd2 = host.scene(dxrs_amd.host.SCENE_DEMO, seed=0)
-    gs2 = dxrs_amd.types.graphics_settings(1920, 1080, frame_index=0, bounces=8, spp=1)
-    cam2 = host.camera(1920, 1080, jitter_index=0)
-    img2, _ = oracle.render(spheres2, materials2, sd2, cam2, gs2, rect=(928, 500, 64, 32), threads=4)
-    np.save(os.path.join(HERE, "c2_crop_928_500_64x32.npy"), img2)
     # the scenes themselves (so a change of the scene generator is caught separately from a change of the estimator)
     np.save(os.path.join(HERE, "scene_small_seed0_spheres.npy"), spheres)
     np.save(os.path.join(HERE, "scene_demo_seed0_spheres.npy"), spheres2)

@@ -1,0 +1,50 @@
+"""The rendered golden cases (tests/golden/*.npy), defined once: tests/golden/make_golden.py writes them from the CPU oracle,
+tests/test_oracle_kat.py checks that the oracle still reproduces them bit for bit (they pin the oracle across rounds -- the
+reference itself has no fixtures for this path), tests/test_gpu_api.py checks the GPU against them.
+
+Each case -> dict(file, spheres, materials, sd, cam, gs, rect, textures)."""
+import copy
+
+import numpy as np
+
+
+def cases(dxrs, host):
+    t = dxrs.types
+    out = []
+    # config C1 (16 spheres, 256x256, 1 spp, 4 bounces, frame 0): 64x64 crop around the hero spheres
+    s, m, sd = host.scene(dxrs.host.SCENE_SMALL, seed=0)
+    out.append(dict(file="c1_crop_96_80_64x64.npy", spheres=s, materials=m, sd=sd, cam=host.camera(256, 256, jitter_index=0),
+                    gs=t.graphics_settings(256, 256, frame_index=0, bounces=4, spp=1), rect=(96, 80, 64, 64), textures=None))
+    # config C2 (demo scene seed 0, 1920x1080, 1 spp, 8 bounces, frame 0): 64x32 crop over the glass / bronze heroes
+    s2, m2, sd2 = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    out.append(dict(file="c2_crop_928_500_64x32.npy", spheres=s2, materials=m2, sd=sd2, cam=host.camera(1920, 1080, jitter_index=0),
+                    gs=t.graphics_settings(1920, 1080, frame_index=0, bounces=8, spp=1), rect=(928, 500, 64, 32), textures=None))
+    # rows N1 + a18: the demo scene after 3 s with its textured objects, lit by the lat-long environment map (yaw pi), 2 spp:
+    # a crop over the Earth and the Moon
+    s3 = host.scene_at_time(0, 3.0)
+    ts, sd3 = host.demo_textures(0, 3.0, environment_map=True, return_scene_data=True)
+    out.append(dict(file="n1_textured_envmap_crop_592_130_96x64.npy", spheres=s3, materials=m2, sd=sd3, cam=host.camera(1280, 720, jitter_index=3),
+                    gs=t.graphics_settings(1280, 720, frame_index=3, bounces=6, spp=2), rect=(592, 130, 96, 64), textures=ts))
+    # row N4: sphere-light direct illumination on the demo scene (its emissive spheres), 1 spp
+    out.append(dict(file="n4_di_crop_560_360_96x48.npy", spheres=s2, materials=m2, sd=sd2, cam=host.camera(1280, 720, jitter_index=1),
+                    gs=t.graphics_settings(1280, 720, frame_index=1, bounces=4, spp=1, di=True), rect=(560, 360, 96, 48), textures=None))
+    # a18, cube map: the small scene under a cube environment made from a function of the direction, rotated
+    from dxrs_amd import textures as T
+    fn = lambda d: np.stack([0.6 + 0.4 * d[..., 0], 0.6 + 0.4 * d[..., 1], 0.9 + 0.6 * d[..., 2] * d[..., 0]], -1)
+    tc = T.TextureSet(len(s))
+    first = tc.add_cube(T.cube_from_function(16, fn))
+    sdc = copy.copy(sd)
+    sdc.EnvironmentLightTextureDescriptor, sdc.IsEnvironmentLightTextureCubeMap = first, 1
+    a = 0.9
+    rot = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
+    for r in range(3):
+        for k in range(3):
+            sdc.EnvironmentLightTransform[4 * r + k] = float(rot[r][k])
+    out.append(dict(file="a18_cube_env_crop_64_64_96x96.npy", spheres=s, materials=m, sd=sdc, cam=host.camera(256, 256, jitter_index=2),
+                    gs=t.graphics_settings(256, 256, frame_index=2, bounces=5, spp=1), rect=(64, 64, 96, 96), textures=tc))
+    return out
+
+
+def tonemap_case(dxrs):
+    """row N3: the C2 crop through the default SDR display transform (ACES filmic + sRGB) -> packed R8G8B8A8"""
+    return "c2_crop_928_500_64x32.npy", "n3_tonemap_aces_srgb_c2_crop.npy", dxrs.types.tonemap_params()

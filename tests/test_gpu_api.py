@@ -59,19 +59,24 @@ def test_call_order_and_argument_errors(dxrs, host):
 
 
 def test_golden_crops(dxrs, host, renderer):
-    """GPU output == committed golden vectors (generated by tests/golden/make_golden.py from the CPU oracle)."""
-    spheres, materials, sd = host.scene(dxrs.host.SCENE_SMALL, seed=0)
-    renderer.set_scene(spheres, materials, sd); renderer.set_camera(host.camera(256, 256, jitter_index=0))
-    renderer.set_constants(dxrs.types.graphics_settings(256, 256, frame_index=0, bounces=4, spp=1))
-    img, _ = renderer.render(rect=(96, 80, 64, 64))
-    gold = np.load(os.path.join(GOLD, "c1_crop_96_80_64x64.npy"))
-    assert np.array_equal(img.view(np.uint32)[..., :3], gold.view(np.uint32)[..., :3])
-    spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
-    renderer.set_scene(spheres, materials, sd); renderer.set_camera(host.camera(1920, 1080, jitter_index=0))
-    renderer.set_constants(dxrs.types.graphics_settings(1920, 1080, frame_index=0, bounces=8, spp=1))
-    img, _ = renderer.render(rect=(928, 500, 64, 32))
-    gold = np.load(os.path.join(GOLD, "c2_crop_928_500_64x32.npy"))
-    assert np.array_equal(img.view(np.uint32)[..., :3], gold.view(np.uint32)[..., :3])
+    """GPU output == committed golden vectors (tests/golden_cases.py, written by tests/golden/make_golden.py from the CPU oracle):
+    C1, C2, textured + environment map, direct illumination, cube environment, and the tone-mapped C2 crop"""
+    import torch
+    import golden_cases
+    for c in golden_cases.cases(dxrs, host):
+        renderer.set_scene(c["spheres"], c["materials"], c["sd"])
+        renderer.set_textures(c["textures"])
+        renderer.set_camera(c["cam"]); renderer.set_constants(c["gs"])
+        img, _ = renderer.render(rect=c["rect"])
+        gold = np.load(os.path.join(GOLD, c["file"]))
+        assert np.array_equal(img.view(np.uint32)[..., :3], gold.view(np.uint32)[..., :3]), c["file"]
+    renderer.set_textures(None)
+    src, dst, params = golden_cases.tonemap_case(dxrs)
+    hdr = torch.from_numpy(np.load(os.path.join(GOLD, src)).reshape(-1, 4)).cuda()
+    ldr = torch.empty(hdr.shape[0], dtype=torch.int32, device="cuda")
+    renderer.tonemap(hdr.data_ptr(), hdr.shape[0], params, ldr.data_ptr())
+    renderer.synchronize()
+    assert np.array_equal(ldr.cpu().numpy().view(np.uint32), np.load(os.path.join(GOLD, dst)).reshape(-1))
 
 
 @pytest.mark.parametrize("flags", [1, 4, 5, 8, 9])  # NO_LDS_SCENE, HOST_LBVH, both, SPLIT_KERNELS, SPLIT + NO_LDS

@@ -1,6 +1,7 @@
 """Known-answer and property tests that pin the CPU oracle to analytic truth.
 The reference has no tests or golden vectors for this path: these KATs are what the oracle is pinned by."""
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -279,3 +280,17 @@ def test_oracle_frame_same_with_and_without_bvh(dxrs, host, oracle, monkeypatch)
     monkeypatch.setenv("ORACLE_NO_BVH", "1")
     b, sb = oracle.render(spheres, materials, sd, cam, gs, threads=8)
     assert sa.rays == sb.rays and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_oracle_reproduces_the_golden_crops(dxrs, host, oracle):
+    """the committed rendered fixtures (tests/golden_cases.py: C1, C2, textured + environment map, direct illumination, cube
+    environment, and the tone-mapped C2 crop) pin the oracle: any change of its arithmetic shows up here, on the CPU"""
+    import golden_cases
+    gold_dir = os.path.join(os.path.dirname(__file__), "golden")
+    for c in golden_cases.cases(dxrs, host):
+        img, _ = oracle.render(c["spheres"], c["materials"], c["sd"], c["cam"], c["gs"], rect=c["rect"], threads=8, textures=c["textures"])
+        gold = np.load(os.path.join(gold_dir, c["file"]))
+        assert np.array_equal(img.view(np.uint32), gold.view(np.uint32)), c["file"]
+        assert np.isfinite(gold).all() and gold[..., :3].std() > 0.01, c["file"]  # a crop with content
+    src, dst, params = golden_cases.tonemap_case(dxrs)
+    assert np.array_equal(oracle.tonemap(np.load(os.path.join(gold_dir, src)), params), np.load(os.path.join(gold_dir, dst)))
