@@ -493,7 +493,14 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         const bool loop_follows_primary = loop_is_main || (spp == 1 && (tail_after == 0 || wf_cap <= 2));
         const bool seg = loop_follows_primary && max_iters > 1 && primary_grid <= kMaxSegs && seg_total <= L.cap_slots && env_u32("PT_SEG", 1u) != 0 && !std::getenv("PT_LOOP_USE_TAIL");
         FrameCounters fc_seg = fc;
-        if (seg) { fc_seg.seg_counts = L.d_seg_counts; fc_seg.n_segs = primary_grid; fc_seg.seg_cap = seg_cap; }
+        // Small frames are bound by the dependent chain of a frame's launches, not by throughput: there the primary pass also
+        // finishes the paths of its own segments and no looping pass is launched -- ONE launch per frame (256x256: 0.0194 ->
+        // 0.0162 ms, 640x384: 0.0397 -> 0.0323, 640x384 at 4 spp: 0.131 -> 0.107, a 1/8 share of a 1080p frame in tiles: 0.0566 ->
+        // 0.0516; a single 1080p frame in flight: 0.190 -> 0.159).  From about half a million slots, with several frames in
+        // flight, the separate looping pass wins (960x540: 0.0426 vs 0.0491 fused, 720p: 0.058 vs 0.076, C2: 0.089 vs 0.096,
+        // C3: 3.60 vs 3.69).  PT_FUSE_LOOP=0/1 overrides.
+        const bool fuse = seg && env_u32("PT_FUSE_LOOP", pm.n_slots < 400000u ? 1u : 0u) != 0;
+        if (seg) { fc_seg.seg_counts = L.d_seg_counts; fc_seg.n_segs = primary_grid; fc_seg.seg_cap = seg_cap; fc_seg.fuse_loop = fuse ? 1u : 0u; }
         // pass 0 generates + traces the primaries and shades them into queue 1; pass k >= 1 consumes queue k
         for (size_t k = 0;; k++) {
             const RayQueue& qin = L.q[k & 1];
@@ -518,7 +525,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
                 return launch_bounce(sv, pm, fp, qin, qout, L.scratch, out, counts + k, counts + k + 1, k <= 1 ? fc_seg : fc, primary, loop, inline2, threads,
                                      primary ? primary_grid : grid_for(items, threads, cap), L.stream);
             }));
-            if (loop || last_possible) break;
+            if (loop || last_possible || (primary && fuse)) break;
         }
     } else {
         const uint32_t trav_grid = grid_for(pm.n_slots, trav_threads, trav_cap);

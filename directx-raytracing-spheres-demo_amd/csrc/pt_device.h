@@ -158,6 +158,7 @@ struct FrameCounters {
     uint32_t* seg_counts;
     uint32_t n_segs;        // == grid size of the primary pass, <= kMaxSegs
     uint32_t seg_cap;       // entries per segment
+    uint32_t fuse_loop;     // 1: the primary pass finishes its own segment itself (no separate looping pass is launched)
 };
 
 constexpr uint32_t kMaxSegs = 2048;

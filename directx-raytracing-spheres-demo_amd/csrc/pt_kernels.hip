@@ -658,7 +658,7 @@ constexpr uint32_t kStaticLdsMargin = (kMaxSegs + 64u) * 4u;
 // queue (wave64 ballot + prefix, one atomic per workgroup) -- one wavefront bounce per launch, 96 B of queue traffic
 // per ray and no hit stream.  kLoop = true: the lane keeps alternating trace and shade_step until its pixel is done
 // (the persistent "tail" form for small queues).
-template <bool kLds, typename StackT, bool kPrimary, bool kLoop, bool kMulti, bool kTex, bool kInline2>
+template <bool kLds, typename StackT, bool kPrimary, bool kLoop, bool kMulti, bool kTex, bool kInline2, bool kFuse>
 // 4 waves/SIMD (<= 128 VGPRs): two 512-thread workgroups per CU with the BVH in LDS (the unconstrained build takes 134
 // VGPRs for the primary variant and drops to 3 waves/SIMD: measured 171 -> 149 us for the two compacting passes at C2)
 __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void bounce_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue qin, RayQueue qout,
@@ -678,6 +678,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
     __shared__ uint32_t s_block_base;
     __shared__ uint32_t s_seg_count;                  // producer side of the segmented hand-over (FrameCounters::seg_counts)
     __shared__ uint32_t s_seg_next;                   // ... and the next 64-slot tile of this workgroup's batches to hand to a wave
+    __shared__ uint32_t s_loop_next;                  // fused form: the next 64 entries of the workgroup's own segment
     __shared__ uint32_t s_seg_prefix[kMaxSegs + 1];   // consumer side: s_seg_prefix[b] = entries in segments < b
     if (kPrimary && blockIdx.x == 0) frame_counters_begin(fc, pm.n_slots);
     const bool seg_out = kPrimary && !kLoop && fc.seg_counts != nullptr;
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
     } else {
         count = kPrimary ? pm.n_slots : *count_in_ptr;
     }
-    if (seg_out && threadIdx.x == 0) { s_seg_count = 0; s_seg_next = 0; }
+    if (seg_out && threadIdx.x == 0) { s_seg_count = 0; s_seg_next = 0; s_loop_next = 0; }
     if (blockIdx.x * blockDim.x >= count) {
         if (seg_out && threadIdx.x == 0) fc.seg_counts[blockIdx.x] = 0;
         return;
@@ -833,26 +834,55 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
             __syncthreads();
         }
     }
+    uint32_t my_loop_rays = 0;
     if (seg_out) {
-        __syncthreads();
-        if (threadIdx.x == 0) fc.seg_counts[blockIdx.x] = s_seg_count;
+        __syncthreads();  // (also orders the queue records written above before the reads below, workgroup scope)
+        const uint32_t n_own = s_seg_count;
+        if (threadIdx.x == 0) {
+            fc.seg_counts[blockIdx.x] = n_own;
+            if (kFuse && n_own) atomicAdd(count_out_ptr, n_own);  // the queue size, for the statistics
+        }
+        if (kFuse) {
+            // Fused form: the workgroup finishes the paths of its OWN segment -- no second launch, no dependency on any other
+            // workgroup; workgroups that are done with their primary tiles run these latency-bound tails while others still trace
+            // primaries.  Waves take 64 entries at a time from a counter in LDS.
+            for (;;) {
+                uint32_t w = 0;
+                if (lane == 0) w = atomicAdd(&s_loop_next, 64u);
+                w = __builtin_amdgcn_readfirstlane(w);
+                if (w >= n_own) break;
+                const uint32_t i = w + lane;
+                if (i < n_own) {
+                    PathState ps = load_path(qout, blockIdx.x * fc.seg_cap + i);
+                    for (;;) {
+                        float t;
+                        uint32_t id;
+                        closest_hit<StackT>(nodes, sph, ids, sv.n, ps.o, ps.d, 0.0f, kInf, stack, blockDim.x, t, id);
+                        if (!shade_step<kMulti, kTex>(sv, pm, fp, scratch, out, ps, t, id)) break;
+                        my_loop_rays++;
+                    }
+                }
+            }
+        }
     }
-    if (kLoop || kIters > 1u) {
+    if (kLoop || kIters > 1u || kFuse) {
         // rays traced in registers: wave reduce, then ONE atomic pair per workgroup (same-address device-scope atomics from
         // 8 XCDs serialise: one per wave made the non-persistent form of this kernel three times slower)
-        unsigned long long total = my_rays;
+        unsigned long long total = my_rays, total2 = kFuse ? my_loop_rays : 0u;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
+        for (int off = 32; off > 0; off >>= 1) {
+            total += __shfl_down(total, off, 64);
+            if (kFuse) total2 += __shfl_down(total2, off, 64);
+        }
+        __shared__ uint32_t s_wave_count2[kFusedThreads / 64];
         __syncthreads();  // s_wave_count is free again
-        if (lane == 0) s_wave_count[wave] = (uint32_t)total;
+        if (lane == 0) { s_wave_count[wave] = (uint32_t)total; if (kFuse) s_wave_count2[wave] = (uint32_t)total2; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            unsigned long long sum = 0;
-            for (uint32_t w = 0; w < (blockDim.x >> 6); w++) sum += s_wave_count[w];
-            if (sum) {
-                atomicAdd(fc.tail_rays, sum);
-                if (!kLoop) atomicAdd(fc.totals + 4, sum);  // running count of the rays a primary pass traced in registers (statistics)
-            }
+            unsigned long long sum = 0, sum2 = 0;
+            for (uint32_t w = 0; w < (blockDim.x >> 6); w++) { sum += s_wave_count[w]; if (kFuse) sum2 += s_wave_count2[w]; }
+            if (sum + sum2) atomicAdd(fc.tail_rays, sum + sum2);
+            if (sum && !kLoop) atomicAdd(fc.totals + 4, sum);  // running count of the rays a primary pass traced in registers (statistics)
         }
     }
 }
@@ -1128,11 +1158,14 @@ hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FramePar
     const bool small = sv.n_nodes < 32767u;
     const uint32_t elem = small ? 2u : 4u;
     const uint32_t lds = (sv.lds_scene ? scene_lds_bytes(sv.n_nodes, sv.n) : 0u) + threads * sv.stack_depth * elem;
-#define PT_BOUNCE6(L, T, P, LP, M, X, I)                                                                                   \
+#define PT_BOUNCE7(L, T, P, LP, M, X, I, F)                                                                                \
     do {                                                                                                                    \
-        if (lds + kStaticLdsMargin > 65536u) (void)hipFuncSetAttribute((const void*)bounce_kernel<L, T, P, LP, M, X, I>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((bounce_kernel<L, T, P, LP, M, X, I>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out, fc); \
+        if (lds + kStaticLdsMargin > 65536u) (void)hipFuncSetAttribute((const void*)bounce_kernel<L, T, P, LP, M, X, I, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((bounce_kernel<L, T, P, LP, M, X, I, F>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out, fc); \
     } while (0)
+/* the fused form (the primary pass finishes its own segments) exists only for the compacting primary pass */
+#define PT_BOUNCE6(L, T, P, LP, M, X, I)                                                                                   \
+    do { if (fc.fuse_loop && P && !LP) PT_BOUNCE7(L, T, P, LP, M, X, I, (P && !LP)); else PT_BOUNCE7(L, T, P, LP, M, X, I, false); } while (0)
 /* the in-register second bounce exists only for the 1-spp compacting primary pass */
 #define PT_BOUNCE5(L, T, P, LP, M, X)                                                                                      \
     do { if (inline2 && P && !LP && !M) PT_BOUNCE6(L, T, P, LP, M, X, (P && !LP && !M)); else PT_BOUNCE6(L, T, P, LP, M, X, false); } while (0)
@@ -1152,6 +1185,7 @@ hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FramePar
 #undef PT_BOUNCE4
 #undef PT_BOUNCE5
 #undef PT_BOUNCE6
+#undef PT_BOUNCE7
     return hipGetLastError();
 }
 

@@ -180,13 +180,15 @@ def test_animated_scene_refit_matches_oracle(dxrs, host, oracle, flags):
 @pytest.mark.parametrize("w,h,spp,bounces,lanes", [(1920, 1080, 1, 8, 1), (1920, 1080, 1, 8, 3), (1280, 720, 4, 6, 2), (333, 211, 1, 3, 1), (640, 360, 2, 1, 1)])
 def test_segmented_and_dense_hand_over_agree(dxrs, host, w, h, spp, bounces, lanes, monkeypatch):
     """the queue between the primary pass and the looping pass is segmented per workgroup by default (no barrier, no global
-    atomic per batch) and dense with PT_SEG=0: same frames bit for bit, same ray counts, same queue sizes --
-    over several frames in flight, so that the per-lane segment counters and work cursors are reused"""
+    atomic per batch), dense with PT_SEG=0, and consumed by the primary pass itself with PT_FUSE_LOOP=1 (the default
+    for small frames): same frames bit for bit, same ray counts, same queue sizes -- over several frames in flight, so that the
+    per-lane segment counters and work cursors are reused"""
     spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
     import torch
     results = {}
-    for seg in ("1", "0"):
+    for seg, fuse in (("1", "0"), ("0", "0"), ("1", "1")):  # segmented, dense, and the single-launch form (the primary pass finishes its own segments)
         monkeypatch.setenv("PT_SEG", seg)
+        monkeypatch.setenv("PT_FUSE_LOOP", fuse)
         r = dxrs.Renderer(frames_in_flight=lanes)
         try:
             r.set_scene(spheres, materials, sd)
@@ -201,10 +203,12 @@ def test_segmented_and_dense_hand_over_agree(dxrs, host, w, h, spp, bounces, lan
                     r.synchronize()
                     frames.append(bufs[k % len(bufs)].cpu().numpy().copy())
             tot = r.totals(reset=True)
-            results[seg] = (frames, int(tot.rays), int(tot.paths), list(r.queue_sizes())[:3])
+            results[seg + fuse] = (frames, int(tot.rays), int(tot.paths), list(r.queue_sizes())[:3])
         finally:
             r.close()
-    a, b = results["1"], results["0"]
-    assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3] and a[3][1] > 0
-    for fa_, fb_ in zip(a[0], b[0]):
-        assert np.array_equal(fa_.view(np.uint32), fb_.view(np.uint32))
+    a = results["10"]
+    assert a[3][1] > 0
+    for b in (results["00"], results["11"]):
+        assert a[1] == b[1] and a[2] == b[2] and a[3][:2] == b[3][:2]
+        for fa_, fb_ in zip(a[0], b[0]):
+            assert np.array_equal(fa_.view(np.uint32), fb_.view(np.uint32))
