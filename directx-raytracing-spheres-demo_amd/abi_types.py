@@ -100,7 +100,7 @@ class PtStats(C.Structure):
         ("rays", C.c_uint64), ("paths", C.c_uint64), ("pixels", C.c_uint64), ("ms_total", C.c_double),
         ("ms_traverse", C.c_double), ("ms_shade", C.c_double), ("traverse_launches", C.c_uint32),
         ("shade_launches", C.c_uint32), ("bytes_algorithmic", C.c_uint64),
-        ("ms_tail", C.c_double), ("tail_launches", C.c_uint32), ("_reserved", C.c_uint32),
+        ("ms_tail", C.c_double), ("tail_launches", C.c_uint32), ("beams_used", C.c_uint32),
         ("rays_first_pass_inline", C.c_uint64),
     ]
 

@@ -28,10 +28,18 @@ constexpr uint32_t kLdsSceneBudget = 64u * 1024u; // stage the BVH in LDS only w
 
 struct EventPair {
     hipEvent_t a, b;
-    int kind;  // 0 primary, 1 traverse, 2 shade
+    int kind;  // 0 primary, 1 traverse / fused bounce, 2 shade, 3 looping pass
 };
 
 }  // namespace
+
+// PT_* tuning knobs (DESIGN.md "Tuning knobs"): environment variables for A/B runs, read ONCE when the context is created --
+// the render path never touches the environment.  -1 = not set (the measured default applies).
+struct Knobs {
+    int split = -1, traverse_blocks_per_cu = -1, fused_threads = -1, no_adaptive_grid = -1, shade_blocks_per_cu = -1, tail_threshold = -1,
+        tail_blocks_per_cu = -1, loop_threads = -1, inline2_min_slots = -1, tail_after = -1, seg = -1, loop_use_tail = -1, fuse_loop = -1,
+        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1;
+};
 
 // Per-frame-in-flight state (see PtContext::lanes).
 struct Lane {
@@ -65,6 +73,13 @@ struct Lane {
     hipEvent_t ev_poll[4] = {};       // queue-size read-backs of the last passes (spp > 1 lagged polling)
     uint32_t scene_n = 0;             // sphere count the private copy was allocated for
     bool scene_private = false;
+    const void* last_out = nullptr;   // output buffer of the lane's latest frame (render_common: repeated buffers inside the window)
+    // object rotations (textured scenes): the lane's own copy, refreshed from PtContext::h_rot when its generation is behind
+    float4* d_rot = nullptr;
+    float4* h_rot_stage = nullptr;    // pinned
+    hipEvent_t ev_rot = nullptr;      // the last upload from h_rot_stage has been consumed
+    uint64_t rot_gen = 0;
+    uint32_t rot_n = 0;
 };
 constexpr uint32_t kMaxLanes = 8;
 
@@ -75,6 +90,7 @@ struct PtContext {
     uint32_t flags = 0;
     uint32_t tile_size = 32;
     uint32_t num_cus = 256;
+    Knobs knobs;
     std::string err;
 
     // scene
@@ -90,7 +106,9 @@ struct PtContext {
     std::vector<std::pair<uint32_t, uint32_t>> tex_dims;  // width, height of every table entry
     TexView* d_tex = nullptr;
     uint32_t* d_tex_maps = nullptr;  // n * 8
-    float4* d_rot = nullptr;         // n
+    float4* d_rot = nullptr;         // n: the rotations as of pt_set_textures (single-lane contexts update it in stream order)
+    std::vector<float4> h_rot;       // latest rotations (pt_update_rotations); lanes pick them up when they next render
+    uint64_t rot_gen = 0;
     bool has_textures = false;
 
     // emissive spheres (row N4)
@@ -125,6 +143,22 @@ struct PtContext {
     float4* d_out = nullptr;
     size_t cap_out = 0;
     uint64_t tot_pixels = 0, tot_paths = 0, tot_fixed_bytes = 0, tot_sec_coeff = 96;  // host-known parts of the totals
+
+    // Primary beams (DESIGN.md "Primary beams"): per-8x8-block candidate sphere lists for the primary pass.  They depend on the
+    // camera pose, the frame geometry and the scene -- not on the frame index or the jitter (the beams are a pixel wider than
+    // the blocks) -- so they are built when a view RESTS: the second consecutive frame with the same key starts the build on
+    // a side stream, the frames after that use the lists; a moving camera or scene never pays for them.
+    struct BeamCache {
+        uint32_t* d_lists = nullptr;   // n_blocks records of 16 dwords
+        size_t cap_blocks = 0;
+        std::vector<uint32_t> key;     // key of the lists in d_lists (valid once ev_ready has completed); empty = none
+        std::vector<uint32_t> last_key;  // key of the previous render call
+        hipStream_t stream = nullptr;
+        hipEvent_t ev_ready = nullptr;   // the build has finished
+        hipEvent_t ev_last_use = nullptr;  // scratch event of a rebuild (orders it after the lanes' frames in flight)
+        bool used = false;
+    } beam;
+    uint64_t scene_gen = 0;  // bumped by everything that changes what a ray can hit
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profiling = false;
@@ -212,6 +246,7 @@ hipError_t sync_all(PtContext* c)
 {
     for (uint32_t i = 0; i < c->n_lanes; i++)
         if (c->lanes[i].stream) { hipError_t e = hipStreamSynchronize(c->lanes[i].stream); if (e != hipSuccess) return e; }
+    if (c->beam.stream) { hipError_t e = hipStreamSynchronize(c->beam.stream); if (e != hipSuccess) return e; }
     return c->stream ? hipStreamSynchronize(c->stream) : hipSuccess;
 }
 
@@ -222,6 +257,30 @@ void free_textures(PtContext* c)
     c->tex_dims.clear();
     free_dev(c->d_tex); free_dev(c->d_tex_maps); free_dev(c->d_rot);
     c->has_textures = false;
+}
+
+// Object rotations follow the frames asynchronously: pt_update_rotations only replaces the host copy and bumps a generation;
+// the lane that renders next uploads them into ITS copy on ITS stream (pinned staging, no wait for the other frames in flight).
+PtStatus sync_lane_rotations(PtContext* c, Lane& L)
+{
+    if (!c->has_textures || c->rot_gen == 0 || L.rot_gen == c->rot_gen) return PT_OK;
+    const uint32_t n = c->n;
+    if (L.rot_n != n) {
+        PT_HIP(c, hipStreamSynchronize(L.stream));
+        free_dev(L.d_rot);
+        if (L.h_rot_stage) { (void)hipHostFree(L.h_rot_stage); L.h_rot_stage = nullptr; }
+        PT_HIP(c, hipMalloc(&L.d_rot, (size_t)n * sizeof(float4)));
+        PT_HIP(c, hipHostMalloc(&L.h_rot_stage, (size_t)n * sizeof(float4)));
+        if (!L.ev_rot) PT_HIP(c, hipEventCreateWithFlags(&L.ev_rot, hipEventDisableTiming));
+        L.rot_n = n;
+    } else {
+        PT_HIP(c, hipEventSynchronize(L.ev_rot));  // the previous upload from the staging buffer has been consumed
+    }
+    std::memcpy(L.h_rot_stage, c->h_rot.data(), (size_t)n * sizeof(float4));
+    PT_HIP(c, hipMemcpyAsync(L.d_rot, L.h_rot_stage, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, L.stream));
+    PT_HIP(c, hipEventRecord(L.ev_rot, L.stream));
+    L.rot_gen = c->rot_gen;
+    return PT_OK;
 }
 
 PtStatus validate_frame(PtContext* c)
@@ -247,7 +306,7 @@ SceneView make_scene_view(const PtContext* c, const Lane* L = nullptr)
     sv.stack_depth = std::max(1u, c->depth);
     sv.lds_scene = c->lds_scene ? 1u : 0u;
     for (int i = 0; i < 4; i++) sv.env[i] = c->sd.EnvironmentLightColor[i];
-    if (c->has_textures) { sv.tex = c->d_tex; sv.tex_maps = c->d_tex_maps; sv.rot = c->d_rot; }
+    if (c->has_textures) { sv.tex = c->d_tex; sv.tex_maps = c->d_tex_maps; sv.rot = (L && L->d_rot && L->rot_gen == c->rot_gen) ? L->d_rot : c->d_rot; }
     sv.env_tex = c->sd.EnvironmentLightTextureDescriptor;  // ~0u == kNoTexture; render_common has checked it against the table
     sv.env_cube = c->sd.IsEnvironmentLightTextureCubeMap ? 1u : 0u;
     for (int r = 0; r < 3; r++)
@@ -270,12 +329,27 @@ FrameParams make_frame_params(const PtContext* c)
     return fp;
 }
 
-uint32_t env_u32(const char* name, uint32_t dflt)
+int env_knob(const char* name)
 {
     const char* v = std::getenv(name);
-    if (!v || !*v) return dflt;
-    return (uint32_t)std::strtoul(v, nullptr, 10);
+    if (!v || !*v) return -1;
+    return (int)std::strtoul(v, nullptr, 10);
 }
+
+Knobs read_knobs()
+{
+    Knobs k;
+    k.split = env_knob("PT_SPLIT"); k.traverse_blocks_per_cu = env_knob("PT_TRAVERSE_BLOCKS_PER_CU"); k.fused_threads = env_knob("PT_FUSED_THREADS");
+    k.no_adaptive_grid = std::getenv("PT_NO_ADAPTIVE_GRID") ? 1 : -1; k.shade_blocks_per_cu = env_knob("PT_SHADE_BLOCKS_PER_CU");
+    k.tail_threshold = env_knob("PT_TAIL_THRESHOLD"); k.tail_blocks_per_cu = env_knob("PT_TAIL_BLOCKS_PER_CU"); k.loop_threads = env_knob("PT_LOOP_THREADS");
+    k.inline2_min_slots = env_knob("PT_INLINE2_MIN_SLOTS"); k.tail_after = env_knob("PT_TAIL_AFTER"); k.seg = env_knob("PT_SEG");
+    k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
+    k.dyn_blocks_per_cu = env_knob("PT_DYN_BLOCKS_PER_CU"); k.debug_counts = std::getenv("PT_DEBUG_COUNTS") ? 1 : -1; k.sah = env_knob("PT_SAH");
+    k.sah_max_spheres = env_knob("PT_SAH_MAX_SPHERES"); k.beams = env_knob("PT_BEAMS");
+    return k;
+}
+
+inline uint32_t knob_or(int v, uint32_t dflt) { return v < 0 ? dflt : (uint32_t)v; }
 
 EventPair* next_events(PtContext* c, int kind)
 {
@@ -341,6 +415,56 @@ void sum_events(PtContext* c, size_t begin, size_t end, PtStats* stats)
     }
 }
 
+// Primary-beam cache (PtContext::BeamCache).  *lists = the cached lists if they were built for this frame's view, else null.
+// The view's key: camera pose (not the jitter: the beams are a pixel wider than their blocks), frame geometry, scene generation.
+PtStatus beam_cache_lookup(PtContext* c, const PixelMap& pm, const uint32_t** lists)
+{
+    *lists = nullptr;
+    auto& B = c->beam;
+    std::vector<uint32_t> key;
+    key.reserve(32);
+    auto put_f = [&](const float* v, int n) { for (int i = 0; i < n; i++) { uint32_t u; std::memcpy(&u, v + i, 4); key.push_back(u); } };
+    put_f(c->cam.Position, 3); put_f(c->cam.RightDirection, 3); put_f(c->cam.UpDirection, 3); put_f(c->cam.ForwardDirection, 3);
+    for (uint32_t v : { pm.mode, pm.img_w, pm.img_h, pm.rx, pm.ry, pm.rw, pm.rh, pm.ts, pm.first, pm.run, pm.stride, pm.n_slots,
+                        (uint32_t)c->scene_gen, (uint32_t)(c->scene_gen >> 32) }) key.push_back(v);
+    if (!B.key.empty() && key == B.key) {
+        *lists = B.d_lists;
+        B.used = true;
+        B.last_key = std::move(key);
+        return PT_OK;
+    }
+    const bool rested = key == B.last_key;  // the second consecutive frame of this view: worth building for
+    B.last_key = key;
+    if (!rested) return PT_OK;
+    if (!B.stream) {
+        PT_HIP(c, hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+        PT_HIP(c, hipEventCreateWithFlags(&B.ev_ready, hipEventDisableTiming));
+        PT_HIP(c, hipEventCreateWithFlags(&B.ev_last_use, hipEventDisableTiming));
+    }
+    const size_t n_blocks = pm.n_slots >> 6;
+    if (n_blocks > B.cap_blocks) {
+        PT_HIP(c, sync_all(c));  // frames in flight may read the old lists
+        PT_HIP(c, hipStreamSynchronize(B.stream));
+        free_dev(B.d_lists);
+        PT_HIP(c, hipMalloc(&B.d_lists, n_blocks * 16u * sizeof(uint32_t)));
+        B.cap_blocks = n_blocks;
+        B.used = false;
+    }
+    // the frames in flight may still read the previous lists: the build waits for every lane (device-side waits only; a
+    // rebuild happens once per resting view, so their cost does not matter)
+    if (B.used)
+        for (uint32_t i = 0; i < c->n_lanes; i++) {
+            PT_HIP(c, hipEventRecord(B.ev_last_use, c->lanes[i].stream));
+            PT_HIP(c, hipStreamWaitEvent(B.stream, B.ev_last_use, 0));
+        }
+    FrameParams fp = make_frame_params(c);
+    PT_HIP(c, launch_beams(make_scene_view(c), pm, fp, B.d_lists, B.stream));
+    PT_HIP(c, hipEventRecord(B.ev_ready, B.stream));
+    B.key = std::move(key);
+    B.used = false;
+    return PT_OK;  // this frame still traverses; the next ones of this view find the lists
+}
+
 // The per-frame launch sequence.  out: device float4 buffer addressed by PixelRef::out_index.
 //
 // Fused schedule (default):  bounce<primary> -> bounce (x S) -> bounce<loop>
@@ -366,11 +490,13 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     // LDS-resident BVH: fused trace+shade passes (traversal is cheap, the hit stream is pure overhead).  BVH in global
     // memory: separate traverse kernels (43 VGPRs, 8 waves/SIMD hide the node-fetch latency; the fused kernel only
     // reaches 4) -- measured 4.3 vs 5.3 ms per frame on the 2^20-sphere scene.
-    const bool split = (c->flags & PT_FLAG_SPLIT_KERNELS) || env_u32("PT_SPLIT", c->lds_scene ? 0u : 1u) != 0;
-    // frames in flight: this frame runs on the next lane (its own stream and work buffers)
+    const bool split = (c->flags & PT_FLAG_SPLIT_KERNELS) || knob_or(c->knobs.split, c->lds_scene ? 0u : 1u) != 0;
+    // every check that can reject the frame comes before any state change (lane rotation, counter parity, markers)
+    if (traverse_lds_bytes_for(c->n_nodes, c->n, std::max(1u, c->depth), c->lds_scene) > kMaxLdsBytes - 9u * 1024u)  // (the kernels' static LDS comes on top)
+        return fail(c, PT_ERR_UNSUPPORTED, "BVH depth needs more traversal-stack LDS than a workgroup can have");
+    // frames in flight: this frame runs on the next lane (its own stream and work buffers); the rotation itself happens
+    // below, once the lane's buffers exist
     Lane& L = c->lanes[c->next_lane];
-    c->last_lane = c->next_lane;
-    c->next_lane = (c->next_lane + 1) % c->n_lanes;
     if (wf_cap + 2 > L.cap_counts && L.cap_counts) {
         // growing the counter arrays: fold what the old ones hold into the totals first
         PT_HIP(c, flush_all_counters(L));
@@ -382,8 +508,8 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     // 1.5 M slots: below that 8 per CU is 4-10 % faster.  (Since the waves of a workgroup draw their tiles dynamically the
     // same holds at spp > 1 -- C3: 3.61 ms with 2 per CU, 3.68 with 8.)
     const bool big_frame = c->lds_scene && pm.n_slots >= 1500000u;
-    const uint32_t trav_cap = c->num_cus * env_u32("PT_TRAVERSE_BLOCKS_PER_CU", big_frame ? 2 : 8);
-    const uint32_t fused_threads = c->lds_scene ? env_u32("PT_FUSED_THREADS", 512) : 256u;
+    const uint32_t trav_cap = c->num_cus * knob_or(c->knobs.traverse_blocks_per_cu, big_frame ? 2 : 8);
+    const uint32_t fused_threads = c->lds_scene ? knob_or(c->knobs.fused_threads, 512) : 256u;
     auto grid_for = [](uint32_t items, uint32_t threads, uint32_t cap) { return std::max(1u, std::min((items + threads - 1) / threads, cap)); };
     // Segmented hand-over from the primary pass to the looping pass (FrameCounters::seg_counts): workgroup b owns the queue
     // entries [b * seg_cap, (b + 1) * seg_cap), seg_cap = the slots it visits -- the queues get that much room
@@ -391,8 +517,26 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     const uint32_t primary_batches = (pm.n_slots + fused_threads - 1) / fused_threads;
     const uint32_t seg_cap = (primary_batches + primary_grid - 1) / primary_grid * fused_threads;
     const size_t seg_total = (size_t)primary_grid * seg_cap;
+    const bool seg_possible = !split && max_iters > 1 && primary_grid <= kMaxSegs && knob_or(c->knobs.seg, 1u) != 0 && c->knobs.loop_use_tail < 0;
     PtStatus st = ensure_buffers(c, L, split ? pm.n_slots : std::max<size_t>(pm.n_slots, seg_total), spp > 1, split, wf_cap + 2, di);
     if (st != PT_OK) return st;
+    if ((st = sync_lane_rotations(c, L)) != PT_OK) return st;
+    c->last_lane = c->next_lane;
+    c->next_lane = (c->next_lane + 1) % c->n_lanes;
+    // Primary beams: use the cached candidate lists when this frame's view is the one they were built for; start a build
+    // (side stream) when the view has rested for two consecutive frames.  PT_BEAMS=0 switches them off, for A/B runs.
+    const uint32_t* beam_lists = nullptr;
+    if (!split && !di && !L.scene_private && c->n_nodes > 0 && knob_or(c->knobs.beams, 1u) != 0 && std::fabs(c->cam.Jitter[0]) <= 0.5f && std::fabs(c->cam.Jitter[1]) <= 0.5f) {
+        if ((st = beam_cache_lookup(c, pm, &beam_lists)) != PT_OK) return st;
+        if (beam_lists) {
+            if (hipEventQuery(c->beam.ev_ready) != hipSuccess) {
+                (void)hipGetLastError();
+                PT_HIP(c, hipStreamWaitEvent(L.stream, c->beam.ev_ready, 0));
+            }
+        }
+    } else {
+        c->beam.last_key.clear();
+    }
     if (L.stream != c->stream) {
         // N frames in flight.  The caller rotates over N output buffers, so this frame may start as soon as the consumer of
         // ITS buffer (queued on the caller's stream right after the render call N calls ago, i.e. before the call N-1 calls
@@ -407,43 +551,52 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
             (void)hipGetLastError();  // hipErrorNotReady is not an error here
             PT_HIP(c, hipStreamWaitEvent(L.stream, marker, 0));
         }
+        // The rotation rule above is the caller's side of the contract; it is also enforced: when `out` is a buffer one of the
+        // other lanes wrote within the window, this frame waits for the marker recorded at the start of THIS call -- i.e. for
+        // everything the caller has queued so far, which includes the wait for that earlier frame and whatever consumed it.
+        // (Costs the overlap of the frames, never correctness.)
+        for (uint32_t i = 0; i < c->n_lanes; i++)
+            if (&c->lanes[i] != &L && c->lanes[i].last_out == out) {
+                PT_HIP(c, hipStreamWaitEvent(L.stream, c->ev_in[c->calls % nl], 0));
+                break;
+            }
+        L.last_out = out;
         c->calls++;
     }
 
     const SceneView sv = make_scene_view(c, &L);
-    const FrameParams fp = make_frame_params(c);
+    FrameParams fp = make_frame_params(c);
+    fp.beam_lists = beam_lists;
     L.parity ^= 1u;
     const FrameCounters fc = make_counters(L, L.parity);
     uint32_t* counts = fc.counts;
-    if (traverse_lds_bytes_for(sv.n_nodes, sv.n, sv.stack_depth, c->lds_scene) > kMaxLdsBytes - 9u * 1024u)  // (the kernels' static LDS comes on top)
-        return fail(c, PT_ERR_UNSUPPORTED, "BVH depth needs more traversal-stack LDS than a workgroup can have");
 
     // Launch grids: a kernel's queue size lives on the device; the host sizes the grid from the queue sizes an
     // earlier frame of the same configuration had (1.25x margin), falling back to the n_slots upper bound.
     const uint64_t signature = ((uint64_t)pm.n_slots << 32) ^ ((uint64_t)bounces << 20) ^ ((uint64_t)spp << 4) ^ pm.mode ^ ((uint64_t)c->n << 40) ^ (split ? 8u : 0u);
-    const bool have_prev = spp == 1 && L.prev_signature == signature && L.h_prev_counts[0] == pm.n_slots && !std::getenv("PT_NO_ADAPTIVE_GRID");
+    const bool have_prev = spp == 1 && L.prev_signature == signature && L.h_prev_counts[0] == pm.n_slots && c->knobs.no_adaptive_grid < 0;
     auto estimate = [&](size_t k) -> uint32_t {
         if (!have_prev || k >= L.cap_counts) return pm.n_slots;
         const uint64_t e = (uint64_t)L.h_prev_counts[k] + L.h_prev_counts[k] / 4 + 64;
         return (uint32_t)std::min<uint64_t>(e, pm.n_slots);
     };
     const uint32_t trav_cap_wide = c->num_cus * 8u;
-    const uint32_t shade_cap = c->num_cus * env_u32("PT_SHADE_BLOCKS_PER_CU", 16);
+    const uint32_t shade_cap = c->num_cus * knob_or(c->knobs.shade_blocks_per_cu, 16);
     // the looping pass: small queues at 1 spp (256 threads, up to 8 workgroups per CU); at spp > 1 of the fused schedule it
     // carries the whole frame after the primary pass (every lane stays busy until its pixel has all its samples), as 2
     // persistent 512-thread workgroups per CU (C3: 6.7 -> 4.8 ms per frame against 33 queue passes + a small looping pass)
-    const bool loop_is_main = spp > 1 && !split && !std::getenv("PT_TAIL_THRESHOLD");
-    const uint32_t tail_cap = c->num_cus * env_u32("PT_TAIL_BLOCKS_PER_CU", loop_is_main ? 2 : 8);
+    const bool loop_is_main = spp > 1 && !split && c->knobs.tail_threshold < 0;
+    const uint32_t tail_cap = c->num_cus * knob_or(c->knobs.tail_blocks_per_cu, loop_is_main ? 2 : 8);
     const uint32_t trav_threads = traverse_threads(c->lds_scene);
     // looping pass: 512-thread workgroups when it carries the frame (spp > 1) and, at 1 spp, for big frames (1080p: 0.0954 ->
     // 0.0887 ms, 4K: 0.329 -> 0.302; at 960x540 and below 256 threads are 6-7 % faster)
-    const uint32_t loop_threads = env_u32("PT_LOOP_THREADS", c->lds_scene && (loop_is_main || big_frame) ? 512u : 256u);
+    const uint32_t loop_threads = knob_or(c->knobs.loop_threads, c->lds_scene && (loop_is_main || big_frame) ? 512u : 256u);
     // Queue-fed passes before the looping kernel (spp == 1).  Fused, large frames: the primary pass also traces the first bounce
     // in registers (bounce_kernel kInline2) and the looping kernel follows it directly -- two launches per frame: 4-10 % faster at
     // every frame size from 256x256 to 4K (PT_INLINE2_MIN_SLOTS switches it off below a slot count, for A/B runs).
-    const bool inline2 = !split && spp == 1 && pm.n_slots >= env_u32("PT_INLINE2_MIN_SLOTS", 0u);
-    const size_t tail_after = env_u32("PT_TAIL_AFTER", split ? 3 : (inline2 ? 0 : 1));
-    const uint32_t tail_threshold = env_u32("PT_TAIL_THRESHOLD", 262144);  // queue size below which spp > 1 switches to it
+    const bool inline2 = !split && spp == 1 && pm.n_slots >= knob_or(c->knobs.inline2_min_slots, 0u);
+    const size_t tail_after = knob_or(c->knobs.tail_after, split ? 3 : (inline2 ? 0 : 1));
+    const uint32_t tail_threshold = knob_or(c->knobs.tail_threshold, 262144);  // queue size below which spp > 1 switches to it
 
     const bool timed = stats != nullptr;
     const size_t ev_begin = c->ev_used;  // this frame's slice of the per-launch event pool
@@ -482,91 +635,100 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         return PT_OK;
     };
 
-    if (fp.di_enabled) {
-        // row N4: the direct-illumination estimate of every primary surface, before the bounce passes read it
-        const uint32_t di_grid = grid_for(pm.n_slots, trav_threads, trav_cap_wide);
-        PT_HIP(c, bracket(1, [&] { return launch_di(sv, pm, fp, L.scratch.di, L.scratch.primary_hit, fc.tail_rays, di_grid, L.stream); }));
-    }
-    if (!split) {
-        // The looping pass follows the primary pass directly (1 spp with the in-register second bounce; spp > 1): the hand-over
-        // is segmented -- no barrier, no global atomic per batch in the primary pass (PT_SEG=0: the dense queue, for A/B runs).
-        const bool loop_follows_primary = loop_is_main || (spp == 1 && (tail_after == 0 || wf_cap <= 2));
-        const bool seg = loop_follows_primary && max_iters > 1 && primary_grid <= kMaxSegs && seg_total <= L.cap_slots && env_u32("PT_SEG", 1u) != 0 && !std::getenv("PT_LOOP_USE_TAIL");
-        FrameCounters fc_seg = fc;
-        // Small frames are bound by the dependent chain of a frame's launches, not by throughput: there the primary pass also
-        // finishes the paths of its own segments and no looping pass is launched -- ONE launch per frame (256x256: 0.0194 ->
-        // 0.0162 ms, 640x384: 0.0397 -> 0.0323, 640x384 at 4 spp: 0.131 -> 0.107, a 1/8 share of a 1080p frame in tiles: 0.0566 ->
-        // 0.0516; a single 1080p frame in flight: 0.190 -> 0.159).  From about half a million slots, with several frames in
-        // flight, the separate looping pass wins (960x540: 0.0426 vs 0.0491 fused, 720p: 0.058 vs 0.076, C2: 0.089 vs 0.096,
-        // C3: 3.60 vs 3.69).  PT_FUSE_LOOP=0/1 overrides.
-        const bool fuse = seg && env_u32("PT_FUSE_LOOP", pm.n_slots < 400000u ? 1u : 0u) != 0;
-        if (seg) { fc_seg.seg_counts = L.d_seg_counts; fc_seg.n_segs = primary_grid; fc_seg.seg_cap = seg_cap; fc_seg.fuse_loop = fuse ? 1u : 0u; }
-        // pass 0 generates + traces the primaries and shades them into queue 1; pass k >= 1 consumes queue k
-        for (size_t k = 0;; k++) {
-            const RayQueue& qin = L.q[k & 1];
-            const RayQueue& qout = L.q[(k + 1) & 1];
-            const bool primary = k == 0;
-            bool go_loop = false, empty = false;
-            if (k > 0) {
-                // queue k exists: is it worth another compacting pass?
-                if ((st = poll(k - 1, empty, go_loop)) != PT_OK) return st;
+    // The launch sequence.  A HIP failure in the middle of it must not leave the caller's stream unordered with respect to the
+    // kernels that were launched: the completion event is recorded and waited for either way (the counter parity stays
+    // flipped -- the kernels that did run used this parity's counters, and the lane's next frame folds them).
+    auto submit = [&]() -> PtStatus {
+        if (fp.di_enabled) {
+            // row N4: the direct-illumination estimate of every primary surface, before the bounce passes read it
+            const uint32_t di_grid = grid_for(pm.n_slots, trav_threads, trav_cap_wide);
+            PT_HIP(c, bracket(1, [&] { return launch_di(sv, pm, fp, L.scratch.di, L.scratch.primary_hit, fc.tail_rays, di_grid, L.stream); }));
+        }
+        if (!split) {
+            // The looping pass follows the primary pass directly (1 spp with the in-register second bounce; spp > 1): the hand-over
+            // is segmented -- no barrier, no global atomic per batch in the primary pass (PT_SEG=0: the dense queue, for A/B runs).
+            const bool loop_follows_primary = loop_is_main || (spp == 1 && (tail_after == 0 || wf_cap <= 2));
+            const bool seg = loop_follows_primary && seg_possible;
+            FrameCounters fc_seg = fc;
+            // Small frames are bound by the dependent chain of a frame's launches, not by throughput: there the primary pass also
+            // finishes the paths of its own segments and no looping pass is launched -- ONE launch per frame (256x256: 0.0194 ->
+            // 0.0162 ms, 640x384: 0.0397 -> 0.0323, 640x384 at 4 spp: 0.131 -> 0.107, a 1/8 share of a 1080p frame in tiles: 0.0566 ->
+            // 0.0516; a single 1080p frame in flight: 0.190 -> 0.159).  From about half a million slots, with several frames in
+            // flight, the separate looping pass wins (960x540: 0.0426 vs 0.0491 fused, 720p: 0.058 vs 0.076, C2: 0.089 vs 0.096,
+            // C3: 3.60 vs 3.69).  PT_FUSE_LOOP=0/1 overrides.
+            const bool fuse = seg && knob_or(c->knobs.fuse_loop, pm.n_slots < 400000u ? 1u : 0u) != 0;
+            if (seg) { fc_seg.seg_counts = L.d_seg_counts; fc_seg.n_segs = primary_grid; fc_seg.seg_cap = seg_cap; fc_seg.fuse_loop = fuse ? 1u : 0u; }
+            // pass 0 generates + traces the primaries and shades them into queue 1; pass k >= 1 consumes queue k
+            for (size_t k = 0;; k++) {
+                const RayQueue& qin = L.q[k & 1];
+                const RayQueue& qout = L.q[(k + 1) & 1];
+                const bool primary = k == 0;
+                bool go_loop = false, empty = false;
+                if (k > 0) {
+                    // queue k exists: is it worth another compacting pass?
+                    if ((st = poll(k - 1, empty, go_loop)) != PT_OK) return st;
+                    if (empty) break;
+                }
+                const bool last_possible = k + 1 >= max_iters;  // no path can have another ray after this pass
+                const bool loop = (k > 0 && go_loop);
+                const uint32_t threads = loop ? loop_threads : fused_threads;
+                const uint32_t items = primary ? pm.n_slots : estimate(k);
+                const uint32_t cap = loop ? tail_cap : trav_cap;
+                if (loop && c->knobs.loop_use_tail >= 0) {
+                    PT_HIP(c, launch_tail(sv, pm, fp, qin, L.scratch, out, counts + k, fc.tail_rays, grid_for(items, kTailThreads, tail_cap), L.stream));
+                    break;
+                }
+                PT_HIP(c, bracket(loop ? 3 : (primary ? 0 : 1), [&] {
+                    return launch_bounce(sv, pm, fp, qin, qout, L.scratch, out, counts + k, counts + k + 1, k <= 1 ? fc_seg : fc, primary, loop, inline2, threads,
+                                         primary ? primary_grid : grid_for(items, threads, cap), L.stream);
+                }));
+                if (loop || last_possible || (primary && fuse)) break;
+            }
+        } else {
+            const uint32_t trav_grid = grid_for(pm.n_slots, trav_threads, trav_cap);
+            PT_HIP(c, bracket(0, [&] { return launch_primary(sv, pm, fp, L.q[0], L.scratch, out, fc, trav_grid, L.stream); }));
+            // shade pass k consumes queue k (counts[k]) and appends to queue k+1; queue k+1 is then traversed, or handed to the tail
+            for (size_t k = 0;; k++) {
+                const RayQueue& qin = L.q[k & 1];
+                const RayQueue& qout = L.q[(k + 1) & 1];
+                PT_HIP(c, bracket(2, [&] { return launch_shade(sv, pm, fp, qin, qout, L.scratch, out, counts + k, counts + k + 1, grid_for(estimate(k), kShadeThreads, shade_cap), L.stream); }));
+                if (k + 1 == max_iters) break;  // no path can have another ray
+                bool go_loop = false, empty = false;
+                if ((st = poll(k, empty, go_loop)) != PT_OK) return st;
                 if (empty) break;
-            }
-            const bool last_possible = k + 1 >= max_iters;  // no path can have another ray after this pass
-            const bool loop = (k > 0 && go_loop);
-            const uint32_t threads = loop ? loop_threads : fused_threads;
-            const uint32_t items = primary ? pm.n_slots : estimate(k);
-            const uint32_t cap = loop ? tail_cap : trav_cap;
-            if (loop && std::getenv("PT_LOOP_USE_TAIL")) {
-                PT_HIP(c, launch_tail(sv, pm, fp, qin, L.scratch, out, counts + k, fc.tail_rays, grid_for(items, kTailThreads, tail_cap), L.stream));
-                break;
-            }
-            PT_HIP(c, bracket(loop ? 3 : (primary ? 0 : 1), [&] {
-                return launch_bounce(sv, pm, fp, qin, qout, L.scratch, out, counts + k, counts + k + 1, k <= 1 ? fc_seg : fc, primary, loop, inline2, threads,
-                                     primary ? primary_grid : grid_for(items, threads, cap), L.stream);
-            }));
-            if (loop || last_possible || (primary && fuse)) break;
-        }
-    } else {
-        const uint32_t trav_grid = grid_for(pm.n_slots, trav_threads, trav_cap);
-        PT_HIP(c, bracket(0, [&] { return launch_primary(sv, pm, fp, L.q[0], L.scratch, out, fc, trav_grid, L.stream); }));
-        // shade pass k consumes queue k (counts[k]) and appends to queue k+1; queue k+1 is then traversed, or handed to the tail
-        for (size_t k = 0;; k++) {
-            const RayQueue& qin = L.q[k & 1];
-            const RayQueue& qout = L.q[(k + 1) & 1];
-            PT_HIP(c, bracket(2, [&] { return launch_shade(sv, pm, fp, qin, qout, L.scratch, out, counts + k, counts + k + 1, grid_for(estimate(k), kShadeThreads, shade_cap), L.stream); }));
-            if (k + 1 == max_iters) break;  // no path can have another ray
-            bool go_loop = false, empty = false;
-            if ((st = poll(k, empty, go_loop)) != PT_OK) return st;
-            if (empty) break;
-            if (go_loop) {
-                PT_HIP(c, bracket(3, [&] { return launch_tail(sv, pm, fp, qout, L.scratch, out, counts + k + 1, fc.tail_rays, grid_for(estimate(k + 1), kTailThreads, tail_cap), L.stream); }));
-                break;
-            }
-            if (!c->lds_scene && sv.n > 1 && env_u32("PT_RAY_REPLACEMENT", 1)) {
-                // persistent waves with ray replacement (heavy-tailed visit counts of large scenes)
-                uint32_t* cursor = counts + L.cap_counts + k + 1;
-                const uint32_t grid = std::min(grid_for(estimate(k + 1), 256u, c->num_cus * 8u), c->num_cus * env_u32("PT_DYN_BLOCKS_PER_CU", 6));
-                PT_HIP(c, bracket(1, [&] { return launch_traverse_dyn(sv, qout, counts + k + 1, cursor, grid, L.stream); }));
-            } else {
-                PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, counts + k + 1, grid_for(estimate(k + 1), trav_threads, trav_cap), L.stream); }));
+                if (go_loop) {
+                    PT_HIP(c, bracket(3, [&] { return launch_tail(sv, pm, fp, qout, L.scratch, out, counts + k + 1, fc.tail_rays, grid_for(estimate(k + 1), kTailThreads, tail_cap), L.stream); }));
+                    break;
+                }
+                if (!c->lds_scene && sv.n > 1 && knob_or(c->knobs.ray_replacement, 1)) {
+                    // persistent waves with ray replacement (heavy-tailed visit counts of large scenes)
+                    uint32_t* cursor = counts + L.cap_counts + k + 1;
+                    const uint32_t grid = std::min(grid_for(estimate(k + 1), 256u, c->num_cus * 8u), c->num_cus * knob_or(c->knobs.dyn_blocks_per_cu, 6));
+                    PT_HIP(c, bracket(1, [&] { return launch_traverse_dyn(sv, qout, counts + k + 1, cursor, grid, L.stream); }));
+                } else {
+                    PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, counts + k + 1, grid_for(estimate(k + 1), trav_threads, trav_cap), L.stream); }));
+                }
             }
         }
-    }
+        return PT_OK;
+    };
+    st = submit();
     // this frame's queue sizes reach h_prev_counts when the lane's next frame folds them (frame_counters_begin): no copy call
     L.prev_signature = signature;  // (the launch-grid estimates above only use them at 1 spp; pt_get_queue_sizes reports them always)
     if (L.stream != c->stream) {
         // whatever the caller queues next on its stream (a gather, a copy, the next use of `out`) sees the finished frame
-        PT_HIP(c, hipEventRecord(L.ev_done, L.stream));
-        PT_HIP(c, hipStreamWaitEvent(c->stream, L.ev_done, 0));
+        const hipError_t e1 = hipEventRecord(L.ev_done, L.stream);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(c->stream, L.ev_done, 0) : e1;
+        if (st == PT_OK && e2 != hipSuccess) st = fail(c, PT_ERR_HIP, std::string("render: completion event: ") + hipGetErrorString(e2));
     }
+    if (st != PT_OK) return st;
     c->tot_pixels += valid_pixels;
     c->tot_paths += valid_pixels * spp;
     c->tot_fixed_bytes += fixed_bytes(split, pm.n_slots, valid_pixels, spp > 1 ? valid_pixels * spp : 0);
     c->tot_sec_coeff = bytes_per_secondary(split);
     if (timed) {
         PT_HIP(c, hipEventRecord(c->ev1, L.stream));
-        if (std::getenv("PT_DEBUG_COUNTS")) {
+        if (c->knobs.debug_counts >= 0) {
             std::vector<uint32_t> hc(L.cap_counts);
             PT_HIP(c, hipMemcpyAsync(hc.data(), counts, L.cap_counts * sizeof(uint32_t), hipMemcpyDeviceToHost, L.stream));
             PT_HIP(c, hipStreamSynchronize(L.stream));
@@ -592,6 +754,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         stats->pixels = valid_pixels;
         stats->paths = valid_pixels * spp;
         stats->bytes_algorithmic = bytes_per_secondary(split) * secondary + fixed_bytes(split, pm.n_slots, valid_pixels, spp > 1 ? valid_pixels * spp : 0);
+        stats->beams_used = beam_lists ? 1u : 0u;
         if (c->profiling) sum_events(c, ev_begin, c->ev_used, stats);
     }
     return PT_OK;
@@ -640,6 +803,7 @@ PtStatus pt_create(const PtConfig* config, PtContext** out_ctx)
     if (!c) return PT_ERR_OOM;
     c->device = config->device;
     c->flags = config->flags;
+    c->knobs = read_knobs();
     c->tile_size = config->tile_size ? config->tile_size : 32;
     if (c->tile_size < 8 || c->tile_size > 1024 || (c->tile_size & (c->tile_size - 1)) != 0) { delete c; return PT_ERR_INVALID_ARG; }  // power of two
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return PT_ERR_HIP; }
@@ -680,6 +844,9 @@ void pt_destroy(PtContext* c)
     for (auto& L : c->lanes) {
         free_lane_buffers(L);
         free_lane_scene(L);
+        free_dev(L.d_rot);
+        if (L.h_rot_stage) (void)hipHostFree(L.h_rot_stage);
+        if (L.ev_rot) (void)hipEventDestroy(L.ev_rot);
         if (L.ev_upload) (void)hipEventDestroy(L.ev_upload);
         for (auto& e : L.ev_poll) if (e) (void)hipEventDestroy(e);
         free_dev(L.d_counts); free_dev(L.d_totals); free_dev(L.d_seg_counts);
@@ -689,6 +856,10 @@ void pt_destroy(PtContext* c)
         if (L.stream && L.stream != c->stream) (void)hipStreamDestroy(L.stream);
     }
     free_dev(c->d_sph); free_dev(c->d_mats); free_dev(c->d_nodes); free_dev(c->d_sph_sorted); free_dev(c->d_sorted_id); free_dev(c->d_lights);
+    free_dev(c->beam.d_lists);
+    if (c->beam.ev_ready) (void)hipEventDestroy(c->beam.ev_ready);
+    if (c->beam.ev_last_use) (void)hipEventDestroy(c->beam.ev_last_use);
+    if (c->beam.stream) (void)hipStreamDestroy(c->beam.stream);
     free_dev(c->d_out);
     for (auto& e : c->ev_in) if (e) (void)hipEventDestroy(e);
     if (c->gpu_builder) lbvh_gpu_destroy(c->gpu_builder);
@@ -745,6 +916,7 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
     c->sd = *sd;
     c->scene_set = true;
     c->accel_valid = false;
+    c->scene_gen++;
     free_textures(c);  // texture maps are per sphere: a new scene starts untextured
     for (auto& L : c->lanes) L.scene_private = false;  // every lane renders the new master scene
     return PT_OK;
@@ -787,7 +959,7 @@ PtStatus pt_build_accel(PtContext* c, PtAccelInfo* info)
         // Small scenes get a SAH topology from the host (the PREFER_FAST_TRACE analogue: 7 % fewer cycles per C2 frame than the
         // Morton-order tree; the build is tens of microseconds at this size); larger ones the device LBVH, whose cost stays
         // O(n) on the GPU.  PT_FLAG_FAST_BUILD / PT_SAH=0 keep the LBVH everywhere.
-        const bool sah = !(c->flags & PT_FLAG_FAST_BUILD) && n > 2 && n <= env_u32("PT_SAH_MAX_SPHERES", kSahMaxSpheres) && env_u32("PT_SAH", 1u) != 0;
+        const bool sah = !(c->flags & PT_FLAG_FAST_BUILD) && n > 2 && n <= knob_or(c->knobs.sah_max_spheres, kSahMaxSpheres) && knob_or(c->knobs.sah, 1u) != 0;
         if (sah) {
             auto t0 = std::chrono::steady_clock::now();
             build_sah_host(c->h_sph.data(), n, c->lbvh);
@@ -813,6 +985,7 @@ PtStatus pt_build_accel(PtContext* c, PtAccelInfo* info)
     c->lds_scene = !(c->flags & PT_FLAG_NO_LDS_SCENE) && scene_bytes <= kLdsSceneBudget
                    && traverse_lds_bytes_for(c->n_nodes, n, std::max(1u, c->depth), true) <= kMaxLdsBytes / 2;
     c->accel_valid = true;
+    c->scene_gen++;
     if (info) {
         std::memset(info, 0, sizeof *info);
         info->leaf_count = n;
@@ -858,6 +1031,7 @@ PtStatus pt_update_spheres(PtContext* c, const PtSphere* spheres, uint32_t n)
     } else {
         PT_HIP(c, hipEventSynchronize(L.ev_upload));  // the previous upload from the staging buffer has been consumed
     }
+    c->scene_gen++;
     std::memcpy(L.h_stage, spheres, (size_t)n * sizeof(PtSphere));
     PT_HIP(c, hipMemcpyAsync(L.d_sph, L.h_stage, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, L.stream));
     PT_HIP(c, hipEventRecord(L.ev_upload, L.stream));
@@ -937,7 +1111,7 @@ PtStatus pt_render(PtContext* c, const PtRect* rect, void* out, int out_is_devic
     if (st != PT_OK) return st;
     PT_HIP(c, hipSetDevice(c->device));
     PtRect r = rect ? *rect : PtRect{ 0, 0, c->gs.RenderSize[0], c->gs.RenderSize[1] };
-    if (r.w == 0 || r.h == 0 || r.x + r.w > c->gs.RenderSize[0] || r.y + r.h > c->gs.RenderSize[1])
+    if (r.w == 0 || r.h == 0 || r.x >= c->gs.RenderSize[0] || r.w > c->gs.RenderSize[0] - r.x || r.y >= c->gs.RenderSize[1] || r.h > c->gs.RenderSize[1] - r.y)
         return fail(c, PT_ERR_INVALID_ARG, "pt_render: rect is empty or outside RenderSize");
     PixelMap pm{};
     pm.mode = 0;
@@ -1111,8 +1285,14 @@ PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_tex
     PT_HIP(c, hipMalloc(&c->d_tex_maps, maps.size() * sizeof(uint32_t)));
     PT_HIP(c, hipMemcpy(c->d_tex_maps, maps.data(), maps.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     PT_HIP(c, hipMalloc(&c->d_rot, (size_t)n * sizeof(float4)));
+    c->h_rot.assign((size_t)n, make_float4(0.f, 0.f, 0.f, 1.f));
+    if (rotations)
+        for (uint32_t i = 0; i < n; i++) c->h_rot[i] = make_float4(rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]);
+    PT_HIP(c, hipMemcpy(c->d_rot, c->h_rot.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));  // (everything was synchronised above)
+    c->rot_gen = 0;  // generation 0 = the master copy; lanes hold private copies from the first pt_update_rotations on
+    for (auto& L : c->lanes) L.rot_gen = 0;
     c->has_textures = true;
-    return pt_update_rotations(c, rotations, n);
+    return PT_OK;
 }
 
 PtStatus pt_update_rotations(PtContext* c, const float* rotations, uint32_t n)
@@ -1120,12 +1300,11 @@ PtStatus pt_update_rotations(PtContext* c, const float* rotations, uint32_t n)
     if (!c) return PT_ERR_INVALID_ARG;
     if (!c->has_textures) return fail(c, PT_ERR_STATE, "pt_update_rotations: the scene has no textures (rotations only orient texture coordinates)");
     if (n != c->n) return fail(c, PT_ERR_INVALID_ARG, "pt_update_rotations: count differs from the scene's sphere count");
-    PT_HIP(c, hipSetDevice(c->device));
-    PT_HIP(c, sync_all(c));
-    std::vector<float4> q((size_t)n, make_float4(0.f, 0.f, 0.f, 1.f));
-    if (rotations)
-        for (uint32_t i = 0; i < n; i++) q[i] = make_float4(rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]);
-    PT_HIP(c, hipMemcpy(c->d_rot, q.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));
+    // No device work and no wait here: the frames in flight keep the rotations they were submitted with; every later render
+    // call uploads these into its lane's own copy on its own stream (sync_lane_rotations), like pt_update_spheres does.
+    for (uint32_t i = 0; i < n; i++)
+        c->h_rot[i] = rotations ? make_float4(rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]) : make_float4(0.f, 0.f, 0.f, 1.f);
+    c->rot_gen++;
     return PT_OK;
 }
 

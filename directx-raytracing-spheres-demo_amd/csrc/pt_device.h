@@ -133,6 +133,7 @@ struct FrameParams {
     float throughput_threshold;
     float inv_spp;        // 1 / (float)spp
     uint32_t di_enabled;  // IsDIEnabled and the scene has emitters: Scratch::di holds this frame's estimate
+    const uint32_t* beam_lists;  // primary beams: one 16-dword record per 64 slots {count, sphere ids}; null = every primary ray traverses
 };
 
 // Per-frame device counters, double buffered by frame parity so that the first kernel of a frame can append to this

@@ -189,6 +189,146 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
     if (kCount && visits) { visits[0] = n_nodes_visited; visits[1] = n_spheres_tested; }
 }
 
+// ------------------------------------------------------------------------------------------------ primary beams
+// Camera rays of one 8x8-pixel block (= one wave64 of the primary pass) share their origin and span a thin pyramid.  One
+// lane per block walks the BVH with that pyramid (four planes through the camera position, a pixel wider than the block on
+// every side: half a pixel for any jitter in [-0.5, 0.5], half a pixel of slack) and lists the spheres whose padded leaf boxes it meets -- at most kBeamListCap; the primary pass then
+// tests exactly those spheres for all 64 rays with wave-uniform control flow instead of 64 divergent stack traversals
+// (DESIGN.md "Primary beams").  The list is a superset of every sphere any ray of the block can hit: a ray inside the
+// pyramid that passes a leaf's padded box (the per-ray slab test's precondition for testing the sphere) means that box
+// meets the pyramid; rounding in the plane tests is covered by the half-pixel widening plus an explicit relative margin.
+// Closest hit over a superset with the same intersect_sphere and the same tie rule = the per-ray traversal's answer, bit
+// for bit.  Record = 16 dwords: { count, original sphere ids[15] }; count > kBeamListCap = overflow, the wave traverses.
+constexpr uint32_t kBeamListCap = 15;
+constexpr uint32_t kBeamRecord = 16;
+
+struct Beam {
+    f3 o;
+    f3 n[4];  // inward unit normals of the four side planes (zero vector = plane that culls nothing)
+};
+
+__device__ __forceinline__ f3 beam_plane(f3 a, f3 b, f3 inside)
+{
+    f3 n = cross(a, b);
+    if (dot(n, inside) < 0.0f) n = -n;
+    const float l2 = dot(n, n);
+    if (!(l2 > 0.0f) || !is_finite(l2)) return make_f3(0.f, 0.f, 0.f);
+    return n * __builtin_amdgcn_rsqf(l2);
+}
+
+__device__ __forceinline__ Beam make_beam(const CameraParams& cam, uint32_t px, uint32_t py)
+{
+    // NDC of the block's outline: its pixel centres lie in [px, px + 8] for every jitter in [-0.5, 0.5] (the host checks the
+    // jitter), widened by half a pixel each way -- the lists serve every frame of a resting view
+    const float xa = ((float)px - 0.5f) * cam.InvW, xb = ((float)px + 8.5f) * cam.InvW;
+    const float ya = ((float)py - 0.5f) * cam.InvH, yb = ((float)py + 8.5f) * cam.InvH;
+    const float nxa = pt_fma(xa, 2.0f, -1.0f), nxb = pt_fma(xb, 2.0f, -1.0f), nya = pt_fma(ya, -2.0f, 1.0f), nyb = pt_fma(yb, -2.0f, 1.0f);
+    const f3 c00 = mad(nya, cam.Up, cam.Right * nxa) + cam.Forward, c10 = mad(nya, cam.Up, cam.Right * nxb) + cam.Forward;
+    const f3 c11 = mad(nyb, cam.Up, cam.Right * nxb) + cam.Forward, c01 = mad(nyb, cam.Up, cam.Right * nxa) + cam.Forward;
+    const f3 mid = (c00 + c11) + (c10 + c01);
+    Beam b;
+    b.o = cam.Position;
+    b.n[0] = beam_plane(c00, c10, mid);
+    b.n[1] = beam_plane(c10, c11, mid);
+    b.n[2] = beam_plane(c11, c01, mid);
+    b.n[3] = beam_plane(c01, c00, mid);
+    return b;
+}
+
+// false = the box lies outside one of the planes for certain (NaNs compare false everywhere: never culled)
+__device__ __forceinline__ bool beam_meets_box(const Beam& b, f3 lo, f3 hi)
+{
+    const f3 l = lo - b.o, h = hi - b.o;
+    const float mag = pt_max(__builtin_fabsf(l.x), __builtin_fabsf(h.x)) + pt_max(__builtin_fabsf(l.y), __builtin_fabsf(h.y)) + pt_max(__builtin_fabsf(l.z), __builtin_fabsf(h.z));
+    const float margin = -4e-6f * mag;
+    bool meets = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const f3 n = b.n[k];
+        // the box corner farthest along the inward normal
+        const float d = pt_max(n.x * l.x, n.x * h.x) + pt_max(n.y * l.y, n.y * h.y) + pt_max(n.z * l.z, n.z * h.z);
+        if (d < margin) meets = false;
+    }
+    return meets;
+}
+
+// leaf: the sphere that encloses the padded leaf box's inscribed sphere (centre = box centre, radius = largest half extent
+// >= r + padding) against the planes
+__device__ __forceinline__ bool beam_meets_leaf(const Beam& b, f3 lo, f3 hi)
+{
+    const f3 c = (lo + hi) * 0.5f - b.o;
+    const f3 e = (hi - lo) * 0.5f;
+    const float r = pt_max(e.x, pt_max(e.y, e.z));
+    const float margin = -(r + 4e-6f * (__builtin_fabsf(c.x) + __builtin_fabsf(c.y) + __builtin_fabsf(c.z) + r));
+    bool meets = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (dot(b.n[k], c) < margin) meets = false;
+    return meets;
+}
+
+template <typename StackT>
+__global__ __launch_bounds__(256) void beam_kernel(SceneView sv, PixelMap pm, FrameParams fp, uint32_t* __restrict__ lists)
+{
+    extern __shared__ float4 smem[];
+    StackT* stack = reinterpret_cast<StackT*>(smem) + threadIdx.x;
+    const uint32_t stride = blockDim.x;
+    const uint32_t n_blocks = pm.n_slots >> 6;
+    const float4* __restrict__ nodes = sv.nodes;
+    for (uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x; tile < n_blocks; tile += gridDim.x * blockDim.x) {
+        uint32_t* rec = lists + (size_t)tile * kBeamRecord;
+        const PixelRef pr = slot_to_pixel(pm, tile << 6);  // the block's first pixel
+        uint32_t count = 0;
+        if (pr.valid) {
+            const Beam b = make_beam(fp.cam, pr.px, pr.py);
+            if (sv.n == 1) {
+                rec[1] = sv.sorted_id[0];
+                count = 1;
+            } else {
+                int node = 0;
+                uint32_t sp = 0;
+                for (;;) {
+                    if (node >= 0) {
+                        const float4 n0 = nodes[node * 4 + 0], n1 = nodes[node * 4 + 1], n2 = nodes[node * 4 + 2], n3 = nodes[node * 4 + 3];
+                        const f3 lo0 = make_f3(n0.x, n0.y, n0.z), hi0 = make_f3(n0.w, n1.x, n1.y), lo1 = make_f3(n1.z, n1.w, n2.x), hi1 = make_f3(n2.y, n2.z, n2.w);
+                        const int c0 = __builtin_bit_cast(int, n3.x), c1 = __builtin_bit_cast(int, n3.y);
+                        const bool h0 = c0 >= 0 ? beam_meets_box(b, lo0, hi0) : (beam_meets_box(b, lo0, hi0) && beam_meets_leaf(b, lo0, hi0));
+                        const bool h1 = c1 >= 0 ? beam_meets_box(b, lo1, hi1) : (beam_meets_box(b, lo1, hi1) && beam_meets_leaf(b, lo1, hi1));
+                        if (h0 && h1) { stack[sp] = stack_encode<StackT>(c1); sp += stride; node = c0; continue; }
+                        if (h0) { node = c0; continue; }
+                        if (h1) { node = c1; continue; }
+                    } else {
+                        if (count < kBeamListCap) rec[1 + count] = sv.sorted_id[~(uint32_t)node];
+                        if (++count > kBeamListCap) break;  // overflow: the wave will traverse per ray
+                    }
+                    if (sp == 0) break;
+                    sp -= stride;
+                    node = stack_decode(stack[sp]);
+                }
+            }
+        }
+        rec[0] = count;
+    }
+}
+
+// Closest hit of a primary ray over its block's candidate list (wave-uniform loop; sphere records come through the scalar
+// cache).  Same intersect_sphere, same tie rule as closest_hit's leaves.
+__device__ __forceinline__ void closest_hit_list(const SceneView& sv, const uint32_t* __restrict__ rec, uint32_t count, f3 o, f3 d, float tmin, float tmax,
+                                                 float& t_out, uint32_t& id_out)
+{
+    float best = tmax;
+    uint32_t best_id = kMissId;
+    for (uint32_t j = 0; j < count; j++) {
+        const uint32_t id = __builtin_amdgcn_readfirstlane(rec[1 + j]);
+        const float4 s = sv.sph[id];
+        float t;
+        if (intersect_sphere(o, d, tmin, kInf, make_f3(s.x, s.y, s.z), s.w, t)) {
+            if (t < best || (t == best && best_id != kMissId && id < best_id)) { best = t; best_id = id; }
+        }
+    }
+    t_out = best; id_out = best_id;
+}
+
 // ------------------------------------------------------------------------------------------------ primary
 template <bool kLds, typename StackT>
 __global__ __launch_bounds__(kTraverseThreads) void primary_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue q,
@@ -760,6 +900,13 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
         }
         bool emit = false;
         PathState ps;
+        // primary beams: this wave's 64 slots are one 8x8-pixel block; its candidate list was made by beam_kernel
+        const uint32_t* beam_rec = nullptr;
+        uint32_t beam_count = ~0u;
+        if (kPrimary && fp.beam_lists) {
+            beam_rec = fp.beam_lists + (size_t)__builtin_amdgcn_readfirstlane(i >> 6) * kBeamRecord;
+            beam_count = __builtin_amdgcn_readfirstlane(beam_rec[0]);
+        }
         if (i < count) {
             bool live = true;
             float tmin = 0.0f, tmax = kInf;
@@ -792,6 +939,9 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
                     if (kPrimary && primary_trace && fp.di_enabled) {
                         const uint2 ph = scratch.primary_hit[i];  // traced by the direct-illumination pass (row N4)
                         t = as_float(ph.x); id = ph.y;
+                    } else if (kPrimary && primary_trace && fp.beam_lists && beam_count <= kBeamListCap) {
+                        closest_hit_list(sv, beam_rec, beam_count, ps.o, ps.d, tmin, tmax, t, id);
+                        if (kMulti) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
                     } else {
                         closest_hit<StackT>(nodes, sph, ids, sv.n, ps.o, ps.d, tmin, tmax, stack, blockDim.x, t, id);
                         if (kMulti && kPrimary && primary_trace) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
@@ -1021,9 +1171,9 @@ template <bool kRgb>
 __global__ void unpack_tiles_kernel(const float4* __restrict__ packed, float4* __restrict__ frame, uint32_t w, uint32_t h, uint32_t ts,
                                     uint32_t tiles_x, uint32_t first0, uint32_t run, uint32_t stride, uint32_t n_parts, uint64_t part_stride)
 {
-    const uint32_t n = w * h;
-    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
-        const uint32_t x = p % w, y = p / w;
+    const uint64_t n = (uint64_t)w * h;  // up to 65535^2 pixels: 64-bit count and index
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t x = (uint32_t)(p % w), y = (uint32_t)(p / w);
         const uint32_t gt = (y / ts) * tiles_x + (x / ts);
         const uint32_t period = gt / stride, res = gt - period * stride;
         if (res < first0) continue;
@@ -1132,6 +1282,18 @@ hipError_t launch_traverse_dyn(const SceneView& sv, const RayQueue& q, const uin
     return hipGetLastError();
 }
 
+hipError_t launch_beams(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, uint32_t* lists, hipStream_t stream)
+{
+    const uint32_t n_blocks = pm.n_slots >> 6;
+    if (n_blocks == 0) return hipSuccess;
+    const bool small = sv.n_nodes < 32767u;
+    const uint32_t lds = 256u * (sv.stack_depth + 1u) * (small ? 2u : 4u);
+    const uint32_t grid = (n_blocks + 255u) / 256u;
+    if (small) hipLaunchKernelGGL((beam_kernel<uint16_t>), dim3(grid), dim3(256), lds, stream, sv, pm, fp, lists);
+    else hipLaunchKernelGGL((beam_kernel<uint32_t>), dim3(grid), dim3(256), lds, stream, sv, pm, fp, lists);
+    return hipGetLastError();
+}
+
 hipError_t launch_tail(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const Scratch& scratch, float4* out,
                        const uint32_t* count_ptr, unsigned long long* tail_rays, uint32_t grid, hipStream_t stream)
 {
@@ -1222,8 +1384,8 @@ hipError_t launch_unpack_tiles(const float4* packed, float4* frame, uint32_t w, 
                                uint32_t run, uint32_t stride, uint32_t n_parts, uint64_t part_stride, bool rgb,
                                hipStream_t stream)
 {
-    const uint32_t n = w * h;
-    const uint32_t grid = (n + 255u) / 256u < 4096u ? (n + 255u) / 256u : 4096u;
+    const uint64_t n = (uint64_t)w * h;
+    const uint32_t grid = (uint32_t)((n + 255u) / 256u < 4096u ? (n + 255u) / 256u : 4096u);
     if (rgb) hipLaunchKernelGGL(unpack_tiles_kernel<true>, dim3(grid), dim3(256), 0, stream, packed, frame, w, h, ts, tiles_x, first0, run, stride, n_parts, part_stride);
     else hipLaunchKernelGGL(unpack_tiles_kernel<false>, dim3(grid), dim3(256), 0, stream, packed, frame, w, h, ts, tiles_x, first0, run, stride, n_parts, part_stride);
     return hipGetLastError();

@@ -19,6 +19,13 @@ def cases(dxrs, host):
     s2, m2, sd2 = host.scene(dxrs.host.SCENE_DEMO, seed=0)
     out.append(dict(file="c2_crop_928_500_64x32.npy", spheres=s2, materials=m2, sd=sd2, cam=host.camera(1920, 1080, jitter_index=0),
                     gs=t.graphics_settings(1920, 1080, frame_index=0, bounces=8, spp=1), rect=(928, 500, 64, 32), textures=None))
+    # configs C3 / C4 (demo scene, 3840x2160; 16 spp x 8 bounces and 64 spp x 16 bounces -- the UI maximum of Source/MyAppData.h:183-188):
+    # 64x48 crops over the glass / bronze heroes; C4 exercises the sample counter + flag packing of the ray record and 64 x 17
+    # iterations per pixel of the looping pass
+    out.append(dict(file="c3_crop_1888_1016_64x48.npy", spheres=s2, materials=m2, sd=sd2, cam=host.camera(3840, 2160, jitter_index=0),
+                    gs=t.graphics_settings(3840, 2160, frame_index=0, bounces=8, spp=16), rect=(1888, 1016, 64, 48), textures=None))
+    out.append(dict(file="c4_crop_1888_1016_64x48.npy", spheres=s2, materials=m2, sd=sd2, cam=host.camera(3840, 2160, jitter_index=0),
+                    gs=t.graphics_settings(3840, 2160, frame_index=0, bounces=16, spp=64), rect=(1888, 1016, 64, 48), textures=None))
     # rows N1 + a18: the demo scene after 3 s with its textured objects, lit by the lat-long environment map (yaw pi), 2 spp:
     # a crop over the Earth and the Moon
     s3 = host.scene_at_time(0, 3.0)

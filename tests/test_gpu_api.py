@@ -212,3 +212,50 @@ def test_segmented_and_dense_hand_over_agree(dxrs, host, w, h, spp, bounces, lan
         assert a[1] == b[1] and a[2] == b[2] and a[3][:2] == b[3][:2]
         for fa_, fb_ in zip(a[0], b[0]):
             assert np.array_equal(fa_.view(np.uint32), fb_.view(np.uint32))
+
+
+def test_primary_beam_cache_follows_the_view(dxrs, host, oracle, renderer):
+    """Primary-beam lists (DESIGN.md "Primary beams") are built when a view rests and must never outlive it: a camera move, a
+    different rect, a new scene or moved spheres each fall back to per-ray traversal until the new view has rested -- every
+    frame bit-identical to the oracle whichever path it took."""
+    from util import count_mismatch
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    w, h = 320, 200
+    gs = dxrs.types.graphics_settings(w, h, frame_index=3, bounces=4, spp=1)
+    cam_a = host.camera(w, h, jitter_index=1)
+    cam_b = host.camera(w, h, position=(1.5, 0.5, -13.0), jitter_index=2)
+    renderer.set_scene(spheres, materials, sd); renderer.set_constants(gs)
+    ref = {}
+
+    def check(cam, name, expect, rect=None, scene=(spheres, materials, sd)):
+        renderer.set_camera(cam)
+        img, st = renderer.render(rect)
+        key = (name, rect, id(scene[0]))
+        if key not in ref:
+            ref[key] = oracle.render(scene[0], scene[1], scene[2], cam, gs, rect=rect, threads=8)
+        assert bool(st.beams_used) == expect, (name, st.beams_used)
+        assert st.rays == ref[key][1].rays and count_mismatch(img, ref[key][0]) == 0, name
+
+    check(cam_a, "a", False); check(cam_a, "a", False); check(cam_a, "a", True)
+    check(cam_b, "b", False)                       # the camera moved: the lists are for another view
+    check(cam_a, "a", True)                        # back: still the cached view (nothing rebuilt in between)
+    check(cam_b, "b", False); check(cam_b, "b", False); check(cam_b, "b", True)  # b rested: rebuilt for b
+    check(cam_b, "b", False, rect=(40, 30, 100, 64))   # another rect = another slot -> pixel map
+    check(cam_b, "b", False, rect=(40, 30, 100, 64)); check(cam_b, "b", True, rect=(40, 30, 100, 64))
+    # the same view with another jitter and frame index keeps the lists (they are a pixel wider than their blocks)
+    gs.FrameIndex = 9
+    renderer.set_constants(gs)
+    ref.clear()
+    cam_b2 = host.camera(w, h, position=(1.5, 0.5, -13.0), jitter_index=5)
+    check(cam_b2, "b2", True, rect=(40, 30, 100, 64))
+    # moved spheres (animation: per-lane private scene copies) never use lists built from the master scene
+    moved = host.scene_at_time(0, 1.25)
+    renderer.update_spheres(moved)
+    scene2 = (moved, materials, sd)
+    check(cam_b2, "b2", False, rect=(40, 30, 100, 64), scene=scene2)
+    renderer.update_spheres(moved)
+    check(cam_b2, "b2", False, rect=(40, 30, 100, 64), scene=scene2)
+    # a new scene
+    small = host.scene(dxrs.host.SCENE_SMALL, seed=0)
+    renderer.set_scene(*small)
+    check(cam_b2, "b2", False, scene=small); check(cam_b2, "b2", False, scene=small); check(cam_b2, "b2", True, scene=small)

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from util import count_mismatch
+from util import count_mismatch, render_rested
 
 pytestmark = pytest.mark.gpu
 
@@ -59,7 +59,7 @@ def test_random_scene_matches_oracle(dxrs, host, oracle, renderer, seed):
     renderer.set_scene(spheres, materials, sd)
     renderer.set_camera(cam)
     renderer.set_constants(gs)
-    img, st = renderer.render()
+    img, st = render_rested(renderer, expect_beams=n > 1)  # first frame: per-ray traversal; third: primary-beam lists
     ref, ost = oracle.render(spheres, materials, sd, cam, gs, threads=8)
     assert st.rays == ost.rays
     assert count_mismatch(img, ref) == 0
@@ -101,7 +101,7 @@ def test_scene_sizes_around_the_lds_limits(dxrs, host, oracle, renderer, n):
     for spp, bounces in ((1, 5), (3, 2)):
         gs = dxrs.types.graphics_settings(w, h, frame_index=n, bounces=bounces, spp=spp)
         renderer.set_constants(gs)
-        img, st = renderer.render()
+        img, st = render_rested(renderer)
         ref, ost = oracle.render(spheres, materials, sd, cam, gs, threads=8)
         assert st.rays == ost.rays
         assert count_mismatch(img, ref) == 0

@@ -4,7 +4,7 @@ Bar (BASELINE.json north_star): per-pixel radiance within 1e-4 relative L2; the 
 import numpy as np
 import pytest
 
-from util import count_mismatch, rel_l2
+from util import count_mismatch, rel_l2, render_rested
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +18,8 @@ def _render_both(dxrs, host, oracle, renderer, scene, w, h, bounces, spp, rect=N
     renderer.set_scene(spheres, materials, sd)
     renderer.set_camera(cam)
     renderer.set_constants(gs)
-    img, stats = renderer.render(rect)
+    # three frames of the view: per-ray BVH traversal for the primaries first, primary-beam candidate lists on the third
+    img, stats = render_rested(renderer, rect, expect_beams=len(spheres) > 1)
     ref, ostats = oracle.render(spheres, materials, sd, cam, gs, rect=rect, threads=8)
     return img, stats, ref, ostats
 
@@ -51,6 +52,27 @@ def test_multi_sample_regeneration(dxrs, host, oracle, renderer, spp, bounces):
     assert stats.rays == ostats.rays
     assert rel_l2(img, ref) <= TOL
     assert count_mismatch(img, ref) == 0
+
+
+def test_c4_crop_max_spp_and_bounces(dxrs, host, oracle, renderer):
+    """BASELINE config C4: 3840x2160, 64 spp, 16 bounces (the UI maximum, Source/MyAppData.h:183-188) -- a 64x48 crop the oracle
+    finishes in seconds (~3 M rays): 64 regenerated samples per pixel share one RNG stream, the sample counter and flags of the
+    48-byte ray record are exercised up to sample 63, and the looping pass runs up to 64 x 17 iterations per pixel."""
+    import os
+    scene = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    rect = (1888, 1016, 64, 48)
+    img, stats, ref, ostats = _render_both(dxrs, host, oracle, renderer, scene, 3840, 2160, 16, 64, rect=rect)
+    assert stats.rays == ostats.rays and stats.paths == ostats.paths == 64 * 48 * 64
+    assert rel_l2(img, ref) <= TOL
+    assert count_mismatch(img, ref) == 0
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "c4_crop_1888_1016_64x48.npy"))
+    assert count_mismatch(img, gold) == 0
+    # the same pixels out of a larger rect whose origin is not 8-aligned (another slot -> pixel mapping, same RNG keys)
+    big = (1861, 1003, 131, 75)
+    renderer.set_constants(dxrs.types.graphics_settings(3840, 2160, frame_index=0, bounces=16, spp=64))
+    img2, _ = renderer.render(big)
+    sub = img2[rect[1] - big[1]: rect[1] - big[1] + rect[3], rect[0] - big[0]: rect[0] - big[0] + rect[2]]
+    assert count_mismatch(sub, gold) == 0
 
 
 def test_frames_and_jitter(dxrs, host, oracle, renderer):

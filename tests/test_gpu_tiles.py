@@ -30,7 +30,8 @@ def tiled_render(dxrs, r, w, h, world, torch):
     return out, rays
 
 
-@pytest.mark.parametrize("w,h,spp,bounces,worlds", [(1920, 1080, 1, 8, (1, 2, 8)), (200, 150, 3, 4, (1, 2, 3, 8)), (3840, 2160, 2, 8, (8,))])
+@pytest.mark.parametrize("w,h,spp,bounces,worlds", [(1920, 1080, 1, 8, (1, 2, 8)), (200, 150, 3, 4, (1, 2, 3, 8)), (3840, 2160, 2, 8, (8,)),
+                                                        (3840, 2160, 64, 16, (8,))])  # the last one is BASELINE config C4 as its 8 ranks render it
 def test_partition_invariance(dxrs, host, renderer, w, h, spp, bounces, worlds):
     import torch
     spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)

@@ -15,3 +15,17 @@ def bits(x):
 def count_mismatch(a, b):
     """number of pixels whose rgb differs in any bit"""
     return int((bits(a)[..., :3] != bits(b)[..., :3]).any(axis=-1).sum())
+
+
+def render_rested(renderer, rect=None, expect_beams=None):
+    """Render the current view three times: the first frame traverses the BVH for every primary ray, the second (the view has
+    rested) starts the primary-beam build, the third takes its primary candidates from the beam lists (DESIGN.md "Primary
+    beams").  All three must agree bit for bit; returns the third (image, stats)."""
+    first, st1 = renderer.render(rect)  # (a view that already rested under other settings may use its lists here: they do not depend on spp / bounces)
+    renderer.render(rect)
+    img, st = renderer.render(rect)
+    if expect_beams is not None:
+        assert bool(st.beams_used) == expect_beams
+    assert st.rays == st1.rays
+    assert np.array_equal(bits(img), bits(first)), "beam-list frame differs from the per-ray traversal frame"
+    return img, st
