@@ -526,7 +526,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     // Primary beams: use the cached candidate lists when this frame's view is the one they were built for; start a build
     // (side stream) when the view has rested for two consecutive frames.  PT_BEAMS=0 switches them off, for A/B runs.
     const uint32_t* beam_lists = nullptr;
-    if (!split && !di && !L.scene_private && c->n_nodes > 0 && knob_or(c->knobs.beams, 1u) != 0 && std::fabs(c->cam.Jitter[0]) <= 0.5f && std::fabs(c->cam.Jitter[1]) <= 0.5f) {
+    if (!split && !L.scene_private && c->n_nodes > 0 && knob_or(c->knobs.beams, 1u) != 0 && std::fabs(c->cam.Jitter[0]) <= 0.5f && std::fabs(c->cam.Jitter[1]) <= 0.5f) {
         if ((st = beam_cache_lookup(c, pm, &beam_lists)) != PT_OK) return st;
         if (beam_lists) {
             if (hipEventQuery(c->beam.ev_ready) != hipSuccess) {
@@ -639,8 +639,9 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     // kernels that were launched: the completion event is recorded and waited for either way (the counter parity stays
     // flipped -- the kernels that did run used this parity's counters, and the lane's next frame folds them).
     auto submit = [&]() -> PtStatus {
-        if (fp.di_enabled) {
-            // row N4: the direct-illumination estimate of every primary surface, before the bounce passes read it
+        if (fp.di_enabled && split) {
+            // row N4, split schedule: the direct-illumination estimate of every primary surface, before the shade passes read it
+            // (the fused schedule's primary pass makes the estimate itself, at the first shading of the primary surface)
             const uint32_t di_grid = grid_for(pm.n_slots, trav_threads, trav_cap_wide);
             PT_HIP(c, bracket(1, [&] { return launch_di(sv, pm, fp, L.scratch.di, L.scratch.primary_hit, fc.tail_rays, di_grid, L.stream); }));
         }

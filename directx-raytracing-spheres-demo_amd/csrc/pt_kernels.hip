@@ -567,11 +567,55 @@ __device__ __forceinline__ HitMaterial hit_material(const SceneView& sv, uint32_
 // kTex = true adds EvaluateMaterial's texture branches + normal mapping (row N1; csrc/pt_texture.h).  It is a template
 // parameter of every kernel that shades, chosen per launch from SceneView::tex_maps, so the kernels of the untextured hot
 // path carry none of it (the textured fused kernels need 122-128 VGPRs against 101-107).
-template <bool kMulti, bool kTex = false>
+// Row N4: the direct-illumination estimate of a primary surface (csrc/pt_light.h; oracle render_pixel): ONE emissive sphere chosen
+// uniformly, a direction uniformly inside the cone it subtends, a shadow ray through `trace` (the ordinary closest-hit query:
+// the emitter must be the first thing it meets), DI = Le * (f_diffuse + f_specular) cos * n_lights / pdf with Le evaluated at the
+// point the shadow ray reaches (EvaluateMaterial: an emissive map modulates it).  Own per-pixel RNG stream.
+template <bool kTex, typename TraceFn>
+__device__ __forceinline__ f3 di_estimate(const SceneView& sv, const FrameParams& fp, uint32_t px, uint32_t py, uint32_t id, f3 d, const HitMaterial& hm,
+                                          TraceFn&& trace, uint32_t& rays)
+{
+    f3 est = make_f3(0.f, 0.f, 0.f);
+    uint32_t rng = rng_init(px, py, fp.frame_index ^ kDiRngSalt);
+    const float u0 = rng_float(rng), u1 = rng_float(rng), u2 = rng_float(rng);
+    const uint32_t light = sv.lights[pick_light(u0, sv.n_lights)];
+    const float4 ls = sv.sph[light];
+    const LightSample s = sample_sphere_cone(hm.hf.P, load3(ls), ls.w, u1, u2);
+    const Surf surf = surf_init(hm.hf.front, hm.hf.N, hm.Ns);
+    if (light != id && s.valid && dot(surf.FrontNg, s.L) > 0.0f) {
+        float t2;
+        uint32_t id2;
+        const f3 so = spawn_origin(hm.hf.P, hm.hf.N, hm.hf.offset, s.L);
+        trace(so, s.L, t2, id2);
+        rays++;
+        if (id2 == light) {
+            const f3 V = -d;
+            float w[3];
+            lobe_weights(hm.bsdf, surf, V, w);
+            const f3 f = bsdf_eval_reflective(hm.bsdf, surf, s.L, V, w);
+            const f3 le = hit_material<kTex>(sv, light, so, s.L, t2, false).emission;
+            est = (le * f) * (s.inv_pdf * (float)sv.n_lights);
+        }
+    }
+    if (!(est.x > 0.0f || est.y > 0.0f || est.z > 0.0f) || !is_finite(est.x) || !is_finite(est.y) || !is_finite(est.z))
+        est = make_f3(0.f, 0.f, 0.f);  // NaN / inf / negative estimates count as no light
+    return est;
+}
+
+struct NoTrace {
+    __device__ __forceinline__ void operator()(f3, f3, float&, uint32_t&) const {}
+};
+
+// kDI = true (primary passes of the fused schedule): the direct-illumination estimate is made HERE, at the first shading of the
+// primary surface, sharing its material / BSDF evaluation; `trace` casts the shadow ray, `di_rays` counts it.  With kDI = false
+// and fp.di_enabled the estimate is read from scratch.di (written by a kDI pass or, in the split schedule, by di_kernel).
+template <bool kMulti, bool kTex = false, bool kDI = false, typename TraceFn = NoTrace>
 __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const Scratch& scratch,
-                                           float4* __restrict__ out, PathState& ps, float t, uint32_t id)
+                                           float4* __restrict__ out, PathState& ps, float t, uint32_t id, TraceFn&& trace = NoTrace(), uint32_t* di_rays = nullptr)
 {
     const uint32_t slot = ps.slot;
+    f3 di_val = make_f3(0.f, 0.f, 0.f);
+    bool di_have = false;  // di_val is this pixel's estimate, made in this call
     for (;;) {
         // sampleRadiance so far is (dirty ? scratch : 0); srad_loaded says whether `srad` holds it
         f3 srad = make_f3(0.f, 0.f, 0.f);
@@ -604,6 +648,11 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
             // ordinary sample value and conditioning on it would bias the frame upward; and a sample that left through the
             // transmission lobe keeps its emission, because DI evaluates the reflective lobes only.
             if (fp.di_enabled && ps.bounce == 1 && !ps.via_t) emission = make_f3(0.f, 0.f, 0.f);
+            if (kDI && fp.di_enabled && ps.bounce == 0 && (!kMulti || ps.sample == 0) && !di_have) {
+                const PixelRef dpr = slot_to_pixel(pm, slot);
+                di_val = di_estimate<kTex>(sv, fp, dpr.px, dpr.py, id, ps.d, hm, trace, *di_rays);
+                di_have = true;
+            }
             const bool t_finite = is_finite(ps.T.x) && is_finite(ps.T.y) && is_finite(ps.T.z);
             if (emission.x != 0.0f || emission.y != 0.0f || emission.z != 0.0f || !t_finite) {
                 if (ps.dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
@@ -653,6 +702,7 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
             ps.d = L;
             ps.bounce++;
             if (srad_changed) { scratch.sample_rad[slot] = make_float4(srad.x, srad.y, srad.z, 0.f); ps.dirty = true; }
+            if (kDI && di_have) scratch.di[slot] = make_float4(di_val.x, di_val.y, di_val.z, 0.f);  // the pass that finishes the pixel adds it
             return true;
         }
         // ---- end of sample: radiance += sampleRadiance (:373)
@@ -669,7 +719,10 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
             if (is_finite(total.x) && is_finite(total.y) && is_finite(total.z)) {
                 res = total * fp.inv_spp;
             }
-            if (fp.di_enabled) { const float4 di = scratch.di[slot]; res = res + load3(di); }  // radiance += DI (:381)
+            if (fp.di_enabled) {  // radiance += DI (:381)
+                if (kDI && di_have) res = res + di_val;
+                else { const float4 di = scratch.di[slot]; res = res + load3(di); }
+            }
             out[pr.out_index] = make_float4(res.x, res.y, res.z, 1.0f);
             return false;
         }
@@ -798,7 +851,7 @@ constexpr uint32_t kStaticLdsMargin = (kMaxSegs + 64u) * 4u;
 // queue (wave64 ballot + prefix, one atomic per workgroup) -- one wavefront bounce per launch, 96 B of queue traffic
 // per ray and no hit stream.  kLoop = true: the lane keeps alternating trace and shade_step until its pixel is done
 // (the persistent "tail" form for small queues).
-template <bool kLds, typename StackT, bool kPrimary, bool kLoop, bool kMulti, bool kTex, bool kInline2, bool kFuse>
+template <bool kLds, typename StackT, bool kPrimary, bool kLoop, bool kMulti, bool kTex, bool kInline2, bool kFuse, bool kDI>
 // 4 waves/SIMD (<= 128 VGPRs): two 512-thread workgroups per CU with the BVH in LDS (the unconstrained build takes 134
 // VGPRs for the primary variant and drops to 3 waves/SIMD: measured 171 -> 149 us for the two compacting passes at C2)
 __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void bounce_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue qin, RayQueue qout,
@@ -936,10 +989,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
                 for (;;) {
                     float t;
                     uint32_t id;
-                    if (kPrimary && primary_trace && fp.di_enabled) {
-                        const uint2 ph = scratch.primary_hit[i];  // traced by the direct-illumination pass (row N4)
-                        t = as_float(ph.x); id = ph.y;
-                    } else if (kPrimary && primary_trace && fp.beam_lists && beam_count <= kBeamListCap) {
+                    if (kPrimary && primary_trace && fp.beam_lists && beam_count <= kBeamListCap) {
                         closest_hit_list(sv, beam_rec, beam_count, ps.o, ps.d, tmin, tmax, t, id);
                         if (kMulti) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
                     } else {
@@ -947,7 +997,12 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
                         if (kMulti && kPrimary && primary_trace) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
                     }
                     primary_trace = false;
-                    emit = shade_step<kMulti, kTex>(sv, pm, fp, scratch, out, ps, t, id);
+                    if (kDI)  // row N4: the first shading of the primary surface also makes its direct-illumination estimate
+                        emit = shade_step<kMulti, kTex, true>(sv, pm, fp, scratch, out, ps, t, id,
+                                                              [&](f3 so, f3 sd, float& t2, uint32_t& id2) { closest_hit<StackT>(nodes, sph, ids, sv.n, so, sd, 0.0f, kInf, stack, blockDim.x, t2, id2); },
+                                                              &my_rays);
+                    else
+                        emit = shade_step<kMulti, kTex>(sv, pm, fp, scratch, out, ps, t, id);
                     if (!emit) break;
                     if (!kLoop && ++iter >= kIters) break;
                     my_rays++;  // a ray spawned and traced inside this kernel (queued rays are counted by counts[])
@@ -1015,7 +1070,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
             }
         }
     }
-    if (kLoop || kIters > 1u || kFuse) {
+    if (kLoop || kIters > 1u || kFuse || kDI) {
         // rays traced in registers: wave reduce, then ONE atomic pair per workgroup (same-address device-scope atomics from
         // 8 XCDs serialise: one per wave made the non-persistent form of this kernel three times slower)
         unsigned long long total = my_rays, total2 = kFuse ? my_loop_rays : 0u;
@@ -1032,7 +1087,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
             unsigned long long sum = 0, sum2 = 0;
             for (uint32_t w = 0; w < (blockDim.x >> 6); w++) { sum += s_wave_count[w]; if (kFuse) sum2 += s_wave_count2[w]; }
             if (sum + sum2) atomicAdd(fc.tail_rays, sum + sum2);
-            if (sum && !kLoop) atomicAdd(fc.totals + 4, sum);  // running count of the rays a primary pass traced in registers (statistics)
+            if (sum && !kLoop && !kDI) atomicAdd(fc.totals + 4, sum);  // running count of the rays a primary pass traced in registers (statistics)
         }
     }
 }
@@ -1077,31 +1132,11 @@ __global__ __launch_bounds__(kTraverseThreads) void di_kernel(SceneView sv, Pixe
             primary_hit[slot] = make_uint2(as_uint(t), id);
             if (id != kMissId) {
                 const HitMaterial hm = hit_material<kTex>(sv, id, o, d, t, true);
-                uint32_t rng = rng_init(pr.px, pr.py, fp.frame_index ^ kDiRngSalt);
-                const float u0 = rng_float(rng), u1 = rng_float(rng), u2 = rng_float(rng);
-                const uint32_t light = sv.lights[pick_light(u0, sv.n_lights)];
-                const float4 ls = sv.sph[light];
-                const LightSample s = sample_sphere_cone(hm.hf.P, load3(ls), ls.w, u1, u2);
-                const Surf surf = surf_init(hm.hf.front, hm.hf.N, hm.Ns);
-                if (light != id && s.valid && dot(surf.FrontNg, s.L) > 0.0f) {
-                    float t2;
-                    uint32_t id2;
-                    closest_hit<StackT>(nodes, sph, ids, sv.n, spawn_origin(hm.hf.P, hm.hf.N, hm.hf.offset, s.L), s.L, 0.0f, kInf, stack, blockDim.x, t2, id2);
-                    my_rays++;
-                    if (id2 == light) {
-                        const f3 V = -d;
-                        float w[3];
-                        lobe_weights(hm.bsdf, surf, V, w);
-                        const f3 f = bsdf_eval_reflective(hm.bsdf, surf, s.L, V, w);
-                        const float4 lm = sv.mats[light * 4 + 1];  // {EmissiveStrength, EmissiveColor}
-                        const f3 le = make_f3(lm.y, lm.z, lm.w) * lm.x;
-                        est = (le * f) * (s.inv_pdf * (float)sv.n_lights);
-                    }
-                }
+                est = di_estimate<kTex>(sv, fp, pr.px, pr.py, id, d, hm,
+                                        [&](f3 so, f3 sd, float& t2, uint32_t& id2) { closest_hit<StackT>(nodes, sph, ids, sv.n, so, sd, 0.0f, kInf, stack, blockDim.x, t2, id2); },
+                                        my_rays);
             }
         }
-        if (!(est.x > 0.0f || est.y > 0.0f || est.z > 0.0f) || !is_finite(est.x) || !is_finite(est.y) || !is_finite(est.z))
-            est = make_f3(0.f, 0.f, 0.f);  // NaN / inf / negative estimates count as no light
         di[slot] = make_float4(est.x, est.y, est.z, 0.0f);
     }
     block_atomic_add(ray_counter, my_rays);
@@ -1320,11 +1355,14 @@ hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FramePar
     const bool small = sv.n_nodes < 32767u;
     const uint32_t elem = small ? 2u : 4u;
     const uint32_t lds = (sv.lds_scene ? scene_lds_bytes(sv.n_nodes, sv.n) : 0u) + threads * sv.stack_depth * elem;
-#define PT_BOUNCE7(L, T, P, LP, M, X, I, F)                                                                                \
+#define PT_BOUNCE8(L, T, P, LP, M, X, I, F, D)                                                                             \
     do {                                                                                                                    \
-        if (lds + kStaticLdsMargin > 65536u) (void)hipFuncSetAttribute((const void*)bounce_kernel<L, T, P, LP, M, X, I, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((bounce_kernel<L, T, P, LP, M, X, I, F>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out, fc); \
+        if (lds + kStaticLdsMargin > 65536u) (void)hipFuncSetAttribute((const void*)bounce_kernel<L, T, P, LP, M, X, I, F, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((bounce_kernel<L, T, P, LP, M, X, I, F, D>), dim3(grid), dim3(threads), lds, stream, sv, pm, fp, qin, qout, scratch, out, count_in, count_out, fc); \
     } while (0)
+/* the direct-illumination estimate (row N4) is made by the compacting primary pass */
+#define PT_BOUNCE7(L, T, P, LP, M, X, I, F)                                                                                \
+    do { if (fp.di_enabled && P && !LP) PT_BOUNCE8(L, T, P, LP, M, X, I, F, (P && !LP)); else PT_BOUNCE8(L, T, P, LP, M, X, I, F, false); } while (0)
 /* the fused form (the primary pass finishes its own segments) exists only for the compacting primary pass */
 #define PT_BOUNCE6(L, T, P, LP, M, X, I)                                                                                   \
     do { if (fc.fuse_loop && P && !LP) PT_BOUNCE7(L, T, P, LP, M, X, I, (P && !LP)); else PT_BOUNCE7(L, T, P, LP, M, X, I, false); } while (0)
@@ -1348,6 +1386,7 @@ hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FramePar
 #undef PT_BOUNCE5
 #undef PT_BOUNCE6
 #undef PT_BOUNCE7
+#undef PT_BOUNCE8
     return hipGetLastError();
 }
 

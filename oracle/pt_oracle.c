@@ -1142,8 +1142,10 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
                 float w[3];
                 lobe_weights(&primary_bsdf, &sv, V, w);
                 v3 f = v_add(bsdf_eval(&primary_bsdf, &sv, L, V, w, 0), bsdf_eval(&primary_bsdf, &sv, L, V, w, 1));
-                const PtMaterial *lm = &mat[light];
-                v3 le = v_scale(V3(lm->EmissiveColor[0], lm->EmissiveColor[1], lm->EmissiveColor[2]), lm->EmissiveStrength);
+                /* the emitter's radiance at the point the shadow ray reaches: Material::GetEmission after EvaluateMaterial (an
+                 * emissive map modulates the constant; LightPreparation.hlsl:84-88 likewise reads the map for its triangles) */
+                const material_eval lme = evaluate_material(tc, &mat[light], &sh);
+                v3 le = v_scale(lme.emissive_color, lme.emissive_strength);
                 DI = v_scale(v_mul(le, f), inv_pdf * (float)lights->n);
             }
         }
