@@ -52,6 +52,8 @@ def main():
                     help="tiled path: shares of the frame rank 0 renders (every other rank renders one; 0 = rank 0 renders everything); "
                          "-1 = measure a few candidates before the warm-up and keep the fastest")
     ap.add_argument("--gather-batch", type=int, default=0, help="tiled path: frames per RCCL gather (0 = frames in flight)")
+    ap.add_argument("--gather", choices=["cabi", "torch"], default="cabi",
+                    help="tiled path, N > 1: the exchange through the C-ABI's pt_gather (default; falls back to torch if its self-check fails) or torch.distributed.gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="the CPU baseline renders every n-th row of each frame")
@@ -135,7 +137,13 @@ def main():
         # the batch must cover the frames in flight: a batch buffer is reused two batches later, and a frame only waits for
         # the caller-stream marker frames_in_flight - 1 calls back (see pt_api.hip render_common)
         batch = max(args.gather_batch or nbuf, nbuf - 1, 1)
-        ex = TileExchange(HipOps(r, dev, set_frame), w, h, rank, world, batch, rehearse=args.force_tiles and world == 1)
+        # The exchange itself: the C-ABI's pt_gather (RCCL grouped send/recv behind include/pt_api.h -- what a C++ host uses),
+        # verified on the live job with a known pattern before it is trusted; torch.distributed.gather otherwise.
+        cabi = False
+        if args.gather == "cabi" and world > 1:
+            cabi = init_cabi_gather(r, dist, torch, dev, rank, world)
+        ex = TileExchange(HipOps(r, dev, set_frame, cabi_gather=cabi), w, h, rank, world, batch, rehearse=args.force_tiles and world == 1)
+        gather_kind = "pt_gather (C-ABI, RCCL send/recv)" if cabi else "torch.distributed.gather (RCCL)"
     if args.animate:
         if args.scene != "demo":
             raise SystemExit("--animate is defined for the demo scene")
@@ -231,7 +239,7 @@ def main():
                             + (", textured (Alien-Metal, Moon, Earth; procedural stand-in images)" if args.textures else "")
                             + (", sphere-light direct illumination (IsDIEnabled)" if args.di else "")
                             + (f", 32x32 tiles interleaved over {world} GPU(s) + RCCL gather to rank 0" if tiled else ""),
-                **({"tile_exchange": {"root_weight": ex.root_weight, "frames_per_gather": ex.batch, "root_tiles": ex.n_root,
+                **({"tile_exchange": {"gather": gather_kind, "root_weight": ex.root_weight, "frames_per_gather": ex.batch, "root_tiles": ex.n_root,
                                       "tiles_per_other_rank": ex.n_other, "autotune": tune_log or None}} if tiled else {}),
                 "frames_in_flight": args.frames_in_flight,
                 "animated": bool(args.animate),
@@ -376,6 +384,36 @@ def main():
     r.close()
     if tiled:
         dist.destroy_process_group()
+
+
+def init_cabi_gather(r, dist, torch, dev, rank, world):
+    """pt_comm_init on every rank (id from rank 0 through the torch process group) + a self-check gather of a known pattern.
+    Returns True when every rank saw it work; any failure is symmetric (all ranks fall back together)."""
+    ok = 1
+    try:
+        ids = [r.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        r.comm_init(ids[0], rank, world)
+        n = 4096
+        send = torch.full((n,), float(rank), dtype=torch.float32, device=dev)
+        recv = torch.zeros((max(world - 1, 1), n), dtype=torch.float32, device=dev)
+        r.gather(send.data_ptr() if rank else 0, recv.data_ptr() if rank == 0 else 0, 4 * n, 0)
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            want = torch.arange(1, world, dtype=torch.float32, device=dev).view(-1, 1).expand(world - 1, n)
+            ok = int(torch.equal(recv, want))
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] rank {rank}: C-ABI gather unavailable ({e}); using torch.distributed.gather", file=sys.stderr)
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        try:
+            r.comm_destroy()
+        except Exception:  # noqa: BLE001
+            pass
+        return False
+    return True
 
 
 if __name__ == "__main__":

@@ -18,6 +18,7 @@ API_SYMBOLS = [
     "pt_create", "pt_destroy", "pt_set_scene", "pt_build_accel", "pt_update_spheres", "pt_refit_accel", "pt_set_camera", "pt_set_constants", "pt_render",
     "pt_set_partition", "pt_tiles_count", "pt_render_tiles", "pt_unpack_tiles", "pt_set_partition_ex", "pt_tiles_count_ex", "pt_unpack_tiles_ex", "pt_tonemap", "pt_accumulate", "pt_set_textures", "pt_update_rotations", "pt_pack_rgb", "pt_unpack_tiles_rgb", "pt_trace_rays", "pt_trace_rays_stats", "pt_accel_download",
     "pt_accel_download_order", "pt_lbvh_build_host", "pt_sah_build_host", "pt_set_profiling", "pt_get_profile", "pt_get_totals", "pt_get_queue_sizes", "pt_synchronize", "pt_last_error", "pt_version",
+    "pt_comm_unique_id", "pt_comm_init", "pt_comm_destroy", "pt_gather", "pt_device_alloc", "pt_device_free", "pt_download",
 ]
 
 
@@ -104,6 +105,14 @@ class HipLib:
         lib.pt_get_queue_sizes.argtypes = [vp, vp, u32, C.POINTER(u32)]
         lib.pt_synchronize.restype = C.c_int
         lib.pt_synchronize.argtypes = [vp]
+        lib.pt_comm_unique_id.restype = C.c_int
+        lib.pt_comm_unique_id.argtypes = [vp]
+        lib.pt_comm_init.restype = C.c_int
+        lib.pt_comm_init.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+        lib.pt_comm_destroy.restype = C.c_int
+        lib.pt_comm_destroy.argtypes = [vp]
+        lib.pt_gather.restype = C.c_int
+        lib.pt_gather.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32]
         lib.pt_last_error.restype = C.c_char_p
         lib.pt_last_error.argtypes = [vp]
         lib.pt_version.restype = C.c_char_p
@@ -240,6 +249,26 @@ class Renderer:
 
     def synchronize(self):
         self._check(self._lib.pt_synchronize(self._ctx))
+
+    # ---- multi-GPU exchange (pt_comm_* / pt_gather): RCCL behind the C-ABI
+    def comm_unique_id(self):
+        """128-byte communicator id (rank 0 makes it and ships it to the other ranks)"""
+        buf = (C.c_ubyte * 128)()
+        st = self._lib.pt_comm_unique_id(buf)
+        if st != 0:
+            raise PtError(st, "pt_comm_unique_id: RCCL could not be loaded" if st == 5 else "pt_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.pt_comm_init(self._ctx, buf, rank, world))
+
+    def comm_destroy(self):
+        self._check(self._lib.pt_comm_destroy(self._ctx))
+
+    def gather(self, send_ptr, recv_ptr, nbytes, root=0):
+        """every rank but `root` sends nbytes from send_ptr; the root receives world - 1 parts into recv_ptr (device pointers)"""
+        self._check(self._lib.pt_gather(self._ctx, C.c_void_p(send_ptr or 0), C.c_void_p(recv_ptr or 0), int(nbytes), int(root)))
 
     def render(self, rect=None, want_stats=True):
         """Render to a host numpy array (h, w, 4) float32.  rect = (x, y, w, h) or None for the full frame."""

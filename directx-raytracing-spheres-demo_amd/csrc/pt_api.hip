@@ -2,6 +2,8 @@
 // memory, LBVH upload, and the per-frame launch sequence of the wavefront kernel set.
 // There is no CPU fallback here by design: without a HIP device pt_create fails.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library itself is loaded at run time (pt_comm_init)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -160,6 +162,10 @@ struct PtContext {
     } beam;
     uint64_t scene_gen = 0;  // bumped by everything that changes what a ray can hit
 
+    // multi-GPU exchange (pt_comm_init / pt_gather): the RCCL communicator of this rank
+    ncclComm_t comm = nullptr;
+    uint32_t comm_rank = 0, comm_world = 1;
+
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profiling = false;
     std::vector<EventPair> ev_pool;
@@ -167,6 +173,43 @@ struct PtContext {
 };
 
 namespace {
+
+// RCCL is resolved at run time, on first use: a single-GPU host never needs it, and inside a process that already carries an
+// RCCL (PyTorch's) the loader hands back that very copy (same SONAME), so one collective library serves the process.
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+
+Rccl& rccl()
+{
+    static Rccl r;
+    if (r.handle || !r.error.empty()) return r;
+    for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) { r.error = std::string("cannot load librccl.so: ") + dlerror(); return r; }
+    auto sym = [&](const char* n) { void* p = dlsym(r.handle, n); if (!p && r.error.empty()) r.error = std::string("librccl.so lacks ") + n; return p; };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!r.error.empty()) { dlclose(r.handle); r.handle = nullptr; }
+    return r;
+}
 
 PtStatus fail(PtContext* ctx, PtStatus st, const std::string& msg)
 {
@@ -841,6 +884,7 @@ void pt_destroy(PtContext* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)sync_all(c);
+    if (c->comm && rccl().handle) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
     free_textures(c);
     for (auto& L : c->lanes) {
         free_lane_buffers(L);
@@ -1469,6 +1513,114 @@ PtStatus pt_get_queue_sizes(PtContext* c, uint32_t* sizes, uint32_t capacity, ui
         if (k > 0 && sizes[k] == 0) break;
     }
     *n = k;
+    return PT_OK;
+}
+
+PtStatus pt_device_alloc(PtContext* c, uint64_t bytes, void** out_device)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!out_device || bytes == 0) return fail(c, PT_ERR_INVALID_ARG, "pt_device_alloc: null pointer or zero size");
+    *out_device = nullptr;
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipMalloc(out_device, (size_t)bytes));
+    return PT_OK;
+}
+
+PtStatus pt_device_free(PtContext* c, void* device)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!device) return PT_OK;
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, sync_all(c));
+    PT_HIP(c, hipFree(device));
+    return PT_OK;
+}
+
+PtStatus pt_download(PtContext* c, const void* device, void* host, uint64_t bytes)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!device || !host) return fail(c, PT_ERR_INVALID_ARG, "pt_download: null pointer");
+    if (bytes == 0) return PT_OK;
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipMemcpyAsync(host, device, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+// ---- multi-GPU exchange (SURVEY 8b pt_gather / 8e) ---------------------------------------------------------------------
+#define PT_NCCL(ctx, expr)                                                                                       \
+    do {                                                                                                         \
+        ncclResult_t r_ = (expr);                                                                                \
+        if (r_ != ncclSuccess) return fail(ctx, PT_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(r_)); \
+    } while (0)
+
+PtStatus pt_comm_unique_id(void* id_out)
+{
+    if (!id_out) return PT_ERR_INVALID_ARG;
+    static_assert(sizeof(ncclUniqueId) == PT_COMM_ID_BYTES, "PT_COMM_ID_BYTES must match ncclUniqueId");
+    Rccl& R = rccl();
+    if (!R.handle) return PT_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    if (R.GetUniqueId(&id) != ncclSuccess) return PT_ERR_HIP;
+    std::memcpy(id_out, &id, sizeof id);
+    return PT_OK;
+}
+
+PtStatus pt_comm_init(PtContext* c, const void* id, uint32_t rank, uint32_t world)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!id || world == 0 || rank >= world) return fail(c, PT_ERR_INVALID_ARG, "pt_comm_init: null id or rank >= world");
+    if (c->comm) return fail(c, PT_ERR_STATE, "pt_comm_init: this context already has a communicator (pt_comm_destroy first)");
+    Rccl& R = rccl();
+    if (!R.handle) return fail(c, PT_ERR_UNSUPPORTED, "pt_comm_init: " + R.error);
+    PT_HIP(c, hipSetDevice(c->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    PT_NCCL(c, R.CommInitRank(&c->comm, (int)world, uid, (int)rank));
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return PT_OK;
+}
+
+PtStatus pt_comm_destroy(PtContext* c)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!c->comm) return PT_OK;
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, sync_all(c));
+    PT_NCCL(c, rccl().CommDestroy(c->comm));
+    c->comm = nullptr;
+    c->comm_rank = 0; c->comm_world = 1;
+    return PT_OK;
+}
+
+PtStatus pt_gather(PtContext* c, const void* send_device, void* recv_device, uint64_t bytes, uint32_t root)
+{
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!c->comm) return fail(c, PT_ERR_STATE, "pt_gather: no communicator (pt_comm_init)");
+    if (root >= c->comm_world) return fail(c, PT_ERR_INVALID_ARG, "pt_gather: root >= world");
+    const bool is_root = c->comm_rank == root;
+    if (bytes == 0) return PT_OK;
+    if (is_root ? (!recv_device && c->comm_world > 1) : !send_device) return fail(c, PT_ERR_INVALID_ARG, "pt_gather: null buffer");
+    PT_HIP(c, hipSetDevice(c->device));
+    Rccl& R = rccl();
+    // Point-to-point over xGMI: the root posts one receive per peer, all in one group, so every inbound link of the root runs
+    // at once; the root's own tiles never travel (it un-swizzles them from where they were rendered).  Stream-ordered on the
+    // context's stream: after the render calls that produced `send`, before whatever the caller queues next.
+    PT_NCCL(c, R.GroupStart());
+    if (is_root) {
+        uint32_t part = 0;
+        for (uint32_t r = 0; r < c->comm_world; r++) {
+            if (r == root) continue;
+            const ncclResult_t e = R.Recv(static_cast<char*>(recv_device) + (size_t)part * bytes, (size_t)bytes, ncclInt8, (int)r, c->comm, c->stream);
+            if (e != ncclSuccess) { (void)R.GroupEnd(); return fail(c, PT_ERR_HIP, std::string("ncclRecv: ") + R.GetErrorString(e)); }
+            part++;
+        }
+    } else {
+        const ncclResult_t e = R.Send(send_device, (size_t)bytes, ncclInt8, (int)root, c->comm, c->stream);
+        if (e != ncclSuccess) { (void)R.GroupEnd(); return fail(c, PT_ERR_HIP, std::string("ncclSend: ") + R.GetErrorString(e)); }
+    }
+    PT_NCCL(c, R.GroupEnd());
     return PT_OK;
 }
 

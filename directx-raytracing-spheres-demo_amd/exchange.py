@@ -20,7 +20,7 @@ runs over RCCL with the HIP renderer (bench.py) and over gloo with the CPU oracl
   per pixel before the gather (one small kernel per batch) and rank 0 un-swizzles with alpha = 1: 25 % fewer bytes into the
   one GPU whose inbound links bound the whole exchange.  Bit-exact (`rgb=False` sends the float4 records as they are).
 
-ops protocol:
+ops protocol (optional: ops.gather_parts(send, recv, nbytes) replaces torch.distributed.gather -- see HipOps):
     ops.alloc(n_px, channels=4) -> torch tensor (n_px, channels) float32 on the exchange device
     ops.pack_rgb(src, n_px, dst)                               float4 records -> 3 floats per pixel (pt_pack_rgb)
     ops.unpack_rgb(...)                                        ops.unpack for 3-float parts (pt_unpack_tiles_rgb)
@@ -99,13 +99,18 @@ class TileExchange:
         if self.sharded:
             # every rank contributes the same number of bytes; rank 0's own tiles never travel (its slot carries a dummy)
             if self.rank == 0:
-                send = self.dummy
+                send = self.dummy  # (torch.distributed.gather wants a contribution from every rank; pt_gather does not)
             elif self.rgb:
                 send = self._send_store[: self.batch * self.own_px]
                 self.ops.pack_rgb(self._own_store[b], self.batch * self.own_px, send)
             else:
                 send = self.own[b].view(self.batch * self.own_px, 4)
-            dist.gather(send, self.gather_list if self.rank == 0 else None, dst=0)
+            if getattr(self.ops, "gather_parts", None):
+                # the C-ABI's exchange (pt_gather: grouped RCCL send/recv on the render stream); rank r's part lands in gathered[r]
+                nbytes = self.batch * self.other_px * (12 if self.rgb else 16)
+                self.ops.gather_parts(None if self.rank == 0 else send, self.gathered[1] if self.rank == 0 else None, nbytes)
+            else:
+                dist.gather(send, self.gather_list if self.rank == 0 else None, dst=0)
         elif self.rehearse and self.rank == 0:
             flat = self.own[b].view(self.batch * self.own_px, 4)
             dist.gather(flat, [self._own_store[b ^ 1][: flat.shape[0]]] if self.world == 1 else None, dst=0)
@@ -148,10 +153,17 @@ class TileExchange:
 
 
 class HipOps:
-    """ops protocol over the HIP renderer (binding.Renderer): `set_frame(k)` installs frame k's camera and constants"""
+    """ops protocol over the HIP renderer (binding.Renderer): `set_frame(k)` installs frame k's camera and constants.
+    cabi_gather=True: the exchange goes through the C-ABI (pt_comm_init has been called on the renderer, pt_gather moves the
+    tiles) -- the path a C++ host takes (host/TileExchange.hpp); otherwise through torch.distributed.gather."""
 
-    def __init__(self, renderer, device, set_frame):
+    def __init__(self, renderer, device, set_frame, cabi_gather=False):
         self.r, self.device, self.set_frame = renderer, device, set_frame
+        if cabi_gather:
+            self.gather_parts = self._gather_parts
+
+    def _gather_parts(self, send, recv, nbytes):
+        self.r.gather(send.data_ptr() if send is not None else 0, recv.data_ptr() if recv is not None else 0, nbytes, 0)
 
     def alloc(self, n_px, channels=4):
         return torch.zeros((max(int(n_px), 1), channels), dtype=torch.float32, device=self.device)

@@ -101,6 +101,9 @@ struct Raytracing {
         m_graphicsSettings.Denoiser = static_cast<uint32_t>(graphicsSettings.Denoiser);
     }
 
+    // the constants alone (what Render does first): for callers that dispatch through the tile entry points (TileExchange.hpp)
+    void UploadConstants() { ThrowIfFailed(pt_set_constants(m_ctx, &m_graphicsSettings), m_ctx, "pt_set_constants"); }
+
     // Raytracing::Render (Raytracing.ixx:106-112): uploads the constants, then DispatchRays(W, H, 1).
     // radiance: W*H float4 host buffer (the reference's Radiance texture, kept at fp32).
     PtStats Render(std::vector<Float4>& radiance)

@@ -227,6 +227,31 @@ PtStatus pt_get_totals(PtContext *ctx, PtStats *totals, int reset);
 /* Queue sizes of the last spp == 1 frame: sizes[k] = rays in queue k (sizes[0] = path slots).  Returns the number of
  * valid entries through *n (0 if none).  Synchronises the stream. */
 PtStatus pt_get_queue_sizes(PtContext *ctx, uint32_t *sizes, uint32_t capacity, uint32_t *n);
+/* Device buffers for callers that do not link a GPU runtime themselves (a C++ host written against this header only): the
+ * packed tile buffers of pt_render_tiles / pt_gather and the assembled frames of pt_unpack_tiles live in such memory.  The
+ * reference's counterpart is the app-owned GPUBuffer / Texture objects handed to the passes (Source/App.cpp:366-368).
+ * pt_device_free waits for the frames in flight; pt_download copies device -> host on the context's stream and waits. */
+PtStatus pt_device_alloc(PtContext *ctx, uint64_t bytes, void **out_device);
+PtStatus pt_device_free(PtContext *ctx, void *device);
+PtStatus pt_download(PtContext *ctx, const void *device, void *host, uint64_t bytes);
+
+/* Multi-GPU exchange of HDR tiles (SURVEY 8b `pt_gather`, 8e): one process per GPU, each with its own context; the frame is
+ * tile-partitioned (pt_set_partition[_ex] / pt_render_tiles) and the packed tile buffers are gathered to the rank that assembles
+ * it.  The reference renders on ONE adapter (Source/DeviceResources.cpp:507 picks a single DXGI adapter); this is the path's
+ * multi-GPU extension.  Collectives are RCCL over xGMI; librccl.so is loaded at run time by pt_comm_unique_id / pt_comm_init
+ * (PT_ERR_UNSUPPORTED when it cannot be), so single-GPU hosts do not depend on it.
+ *   pt_comm_unique_id  rank 0 creates the 128-byte id and ships it to the other ranks (file, socket, launcher environment).
+ *   pt_comm_init       collective over all `world` ranks (ncclCommInitRank); the context owns the communicator.
+ *   pt_gather          on the context's stream, ordered after the render calls queued before it: every rank other than `root`
+ *                      sends `bytes` bytes from send_device (recv_device ignored); the root receives world - 1 parts, the part of
+ *                      rank r at recv_device + (r < root ? r : r - 1) * bytes (send_device ignored: its own tiles never travel).
+ *                      One grouped ncclSend/ncclRecv exchange, so all inbound links of the root are used at once. */
+#define PT_COMM_ID_BYTES 128
+PtStatus pt_comm_unique_id(void *id_out);
+PtStatus pt_comm_init(PtContext *ctx, const void *id, uint32_t rank, uint32_t world);
+PtStatus pt_comm_destroy(PtContext *ctx);
+PtStatus pt_gather(PtContext *ctx, const void *send_device, void *recv_device, uint64_t bytes, uint32_t root);
+
 PtStatus pt_synchronize(PtContext *ctx);
 
 const char *pt_last_error(PtContext *ctx);

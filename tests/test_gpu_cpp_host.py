@@ -90,3 +90,54 @@ def test_cpp_host_environment_map_matches_python_path_and_oracle(dxrs, host, ora
     sky_only = host.scene(dxrs.host.SCENE_DEMO, seed=0)[2]
     plain, _ = oracle.render(spheres, materials, sky_only, cam, gs, threads=8, textures=host.demo_textures(0, 3.0))
     assert not np.array_equal(plain.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def tiles_exe(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("cpp") / "host_tiles")
+    subprocess.run(["g++", "-std=c++20", "-O1", "-Wall", "-I", os.path.join(PKG, "host"), os.path.join(ROOT, "tests", "cpp", "host_tiles.cpp"),
+                    "-o", exe, "-L", PKG, "-lpt_hip", f"-Wl,-rpath,{PKG}"], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("w,h,bounces,spp,frames,batch,weight", [(320, 200, 4, 1, 5, 2, 1), (257, 131, 3, 2, 3, 4, 3)])
+def test_cpp_host_renders_tiles_through_the_cabi_exchange(dxrs, host, renderer, tiles_exe, tmp_path, w, h, bounces, spp, frames, batch, weight):
+    """The C++ host's tiled path (host/TileExchange.hpp over pt_device_alloc / pt_render_tiles / pt_gather / pt_unpack_tiles_ex /
+    pt_download) with one rank -- the call sequence of the N-rank job, including pt_comm_init on a one-rank RCCL communicator
+    created from C++ -- assembles the same frame, bit for bit, as a plain full-frame render."""
+    out = str(tmp_path / "tiles.f32")
+    res = subprocess.run([tiles_exe, str(w), str(h), str(bounces), str(spp), str(frames), str(batch), str(weight), out], capture_output=True, text=True,
+                         env={**os.environ, "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert res.returncode == 0, res.stdout + res.stderr
+    img_cpp = np.fromfile(out, dtype=np.float32).reshape(h, w, 4)
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    k = frames - 1
+    renderer.set_scene(spheres, materials, sd)
+    renderer.set_camera(host.camera(w, h, jitter_index=k))
+    renderer.set_constants(dxrs.types.graphics_settings(w, h, frame_index=k, bounces=bounces, spp=spp))
+    img_py, _ = renderer.render()
+    assert np.array_equal(img_cpp.view(np.uint32), img_py.view(np.uint32))
+
+
+def test_cabi_communicator_and_gather_one_rank(dxrs):
+    """pt_comm_unique_id / pt_comm_init / pt_gather / pt_comm_destroy inside the Python process (RCCL is resolved at run time --
+    here the copy PyTorch already carries): a one-rank communicator, a gather that has nothing to move, state errors."""
+    import torch
+    r = dxrs.Renderer(device=0)
+    try:
+        with pytest.raises(dxrs.PtError):
+            r.gather(0, 0, 16)  # no communicator yet
+        uid = r.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        r.comm_init(uid, 0, 1)
+        with pytest.raises(dxrs.PtError):
+            r.comm_init(uid, 0, 1)  # already has one
+        buf = torch.zeros(1024, dtype=torch.float32, device="cuda")
+        r.gather(0, buf.data_ptr(), 4096, 0)
+        r.synchronize()
+        with pytest.raises(dxrs.PtError):
+            r.gather(0, buf.data_ptr(), 4096, 3)  # root outside the communicator
+        r.comm_destroy()
+        r.comm_destroy()  # idempotent
+    finally:
+        r.close()
