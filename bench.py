@@ -251,104 +251,8 @@ def main():
 
     # ---- roofline of the dominant kernel class, from the per-launch HIP events of the timed region itself (this rank)
     if not args.no_roofline and rank == 0:
-        n_f = args.steps
-        my_pixels = tot_ev.pixels / n_f
-        my_secondary = (tot_ev.rays - tot_ev.pixels) / n_f
-        n_wf = prof.traverse_launches // n_f  # compacting passes per frame (incl. the primary pass)
-        qs = queue_sizes
-        my_rays = tot_ev.rays / n_f
-        inline1 = tot_ev.rays_first_pass_inline / n_f  # bounce-1 rays the primary pass traced in registers (never queued)
-        if qs and len(qs) > n_wf >= 1:
-            wf_in, wf_out, loop_in = sum(qs[1:n_wf]), sum(qs[1:n_wf + 1]), qs[n_wf]
-            px_wf = qs[0] - loop_in if world == 1 else my_pixels - loop_in
-        else:  # no per-queue sizes (spp > 1): every secondary ray is written once and read once
-            wf_in = wf_out = my_secondary; loop_in = 0; px_wf = my_pixels
-        # (1) SURVEY 8(d) accounting -- the figure `achieved` uses: 160 B per ray (2R + 2H + R' of the wavefront formulation) +
-        #     40 B per path, times the rays traced / paths finished by the launches of the class.
-        rays_wf = my_pixels + inline1 + wf_in          # compacting passes: primaries, in-register bounce-1 rays, queued rays
-        rays_loop = max(my_rays - rays_wf, 0.0)        # everything else is traced by the looping pass
-        paths_wf, paths_loop = px_wf * args.spp, loop_in * args.spp
-        survey_wf = (160 * rays_wf + 40 * paths_wf) * n_f
-        survey_loop = (160 * rays_loop + 40 * paths_loop) * n_f
-        # (2) what THIS implementation has to move (DESIGN.md byte model, fused schedule): a compacting pass reads 48 B per ray of
-        #     its input queue, writes 48 B per ray it emits and 16 B per pixel it finishes; the looping pass reads 48 B per queued
-        #     ray and writes 16 B per pixel it finishes -- rays kept in registers cost nothing.
-        impl_wf = (48 * wf_in + 48 * wf_out + 16 * px_wf) * n_f
-        impl_loop = (48 * loop_in + 16 * loop_in) * n_f
-        split = prof.shade_launches > 0
-        b_impl = None
-        if split:  # split schedule (BVH in global memory): traverse-type launches read o,d and write hits; see DESIGN.md
-            name, b, ms, n = "traverse_kernel (+ primary_kernel)", (40 * my_secondary + 56 * qs[0] if qs else 40 * my_secondary) * n_f, prof.ms_traverse, prof.traverse_launches
-        elif prof.ms_traverse >= prof.ms_tail:
-            name, b, b_impl, ms, n = "bounce_kernel (primary / compacting trace+shade passes)", survey_wf, impl_wf, prof.ms_traverse, prof.traverse_launches
-        else:
-            name, b, b_impl, ms, n = "bounce_kernel<loop> (looping trace+shade pass)", survey_loop, impl_loop, prof.ms_tail, prof.tail_launches
-        achieved = (b / n) / (ms / n * 1e-3) / 1e9 if n and ms > 0 else 0.0
-        traffic = None
-        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the guide prescribes)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pmc.get("workload") == f"{args.scene}-{w}x{h}-{args.spp}spp-{args.bounces}b" and not split and not args.di and not args.textures and not args.env_map:
-                key = "bounce<loop>" if "loop" in name else "bounce<wavefront>"
-                traffic = pmc[key]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
-        # the same kernel class running ALONE on the GPU (one frame at a time, a few frames): with several frames in flight the
-        # launches of consecutive frames share the machine, which stretches every per-launch duration above
-        excl = None
-        if args.frames_in_flight > 1 and not split:
-            r1 = dxrs_amd.Renderer(device=local_rank, stream=stream, frames_in_flight=1)
-            r1.set_scene(spheres, materials, sd); r1.set_constants(gs)
-            if tex is not None:
-                r1.set_textures(tex)
-            if tiled:
-                r1.set_partition_ex(*ex.range)
-            for k in range(3):
-                step_on(r1, k)
-            r1.set_profiling(True)
-            for k in range(20):
-                step_on(r1, args.warmup + k)
-            p1 = r1.profile(reset=True)
-            r1.close()
-            ms1, n1 = (p1.ms_tail, p1.tail_launches) if "loop" in name else (p1.ms_traverse, p1.traverse_launches)
-            if n1 and ms1 > 0:
-                excl = {"avg_launch_ms": ms1 / n1, "achieved": (b / n) / (ms1 / n1 * 1e-3) / 1e9}
-                excl["frac"] = excl["achieved"] / HBM_PEAK_GBS
-                if b_impl is not None:
-                    excl["implementation_gbs"] = (b_impl / n) / (ms1 / n1 * 1e-3) / 1e9
-        # the bound that actually binds: VALU issue.  Instruction counts per launch from the committed SQ-counter pass
-        # (profiles/sq_counters.json, made by profiles/collect.sh + make_sq_counters.py); 4 cycles per wave64 VALU instruction
-        # on 256 CUs x 4 SIMDs at the measured 2.35 GHz (tools/experiments/clock.hip)
-        valu = None
-        try:
-            if pmc.get("workload") == f"{args.scene}-{w}x{h}-{args.spp}spp-{args.bounces}b" and not split and not args.textures and not args.env_map and not tiled and not args.di:
-                sq = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))["kernels"]
-                per_frame = sum(k["valu_insts_per_launch"] for k in sq.values())
-                bound_ms = per_frame * 4 / 1024 / 2.35e9 * 1e3
-                valu = {"wave_insts_per_frame": per_frame, "valu_bound_ms_per_frame": bound_ms, "frac_of_valu_bound": bound_ms / ms_per_step,
-                        "source": "profiles/sq_counters.json (rocprofv3 SQ_INSTS_VALU per launch, one frame in flight)"}
-        except Exception:
-            pass
-        result["roofline"] = {
-            "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "bytes_per_launch": b / max(n, 1), "avg_launch_ms": ms / max(n, 1), "launches_per_frame": n / n_f,
-            "accounting": ("traverse-type launches of the split schedule: 40 B per secondary ray + 56 B per primary slot (DESIGN.md)" if split else
-                           "SURVEY 8(d): 160 B per ray traced + 40 B per path finished by these launches"),
-            "implementation_bytes_per_launch": None if b_impl is None else b_impl / max(n, 1),
-            "implementation_gbs": None if b_impl is None or not (n and ms > 0) else (b_impl / n) / (ms / n * 1e-3) / 1e9,
-            "rays_per_launch": None if split else (rays_wf if "loop" not in name else rays_loop) / max(n / n_f, 1),
-            "compacting_ms_per_frame": prof.ms_traverse / n_f, "shade_ms_per_frame": prof.ms_shade / n_f, "loop_ms_per_frame": prof.ms_tail / n_f,
-            "ms_per_step_with_events": elapsed_ev / n_f * 1e3,
-            "exclusive": excl,
-            "valu": valu,
-            "sustained_gbs": (b / n_f) / (elapsed / args.steps) / 1e9,
-            "note": "achieved/frac: algorithmic bytes (SURVEY 8(d) per-ray / per-path figures x the rays traced and paths finished by the "
-                    "launches) / per-launch HIP events over a second timed region of the same K steps (they agree with the rocprofv3 "
-                    "kernel-trace averages of this command); with N frames in flight the launches of consecutive frames overlap and share "
-                    "the GPU, so each lasts longer than when it runs alone ('exclusive': one frame at a time). 'implementation_*' = the bytes "
-                    "this fused implementation actually has to move (rays that stay in registers cost none; 'traffic' is the rocprofv3 "
-                    "measurement of it); 'valu' = the bound that really binds; 'sustained_gbs' = algorithmic bytes per frame / ms_per_step",
-        }
+        result["roofline"] = roofline_object(args, w, h, world, tiled, prof, tot_ev, queue_sizes, elapsed, elapsed_ev, ms_per_step, len(spheres),
+                                             lambda: exclusive_profile(dxrs_amd, local_rank, stream, spheres, materials, sd, gs, tex, tiled, ex if tiled else None, step_on, args))
 
     # ---- CPU baseline: the scalar oracle on this node's host cores, bounded sample of the same frame (rank 0, N = 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -384,6 +288,125 @@ def main():
     r.close()
     if tiled:
         dist.destroy_process_group()
+
+
+def load_counters(workload):
+    """profiles/counters_<workload>.json (rocprofv3 PMC passes, made by profiles/collect.sh) -- only if it was measured on the
+    kernel sources this run uses; otherwise (None, reason)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_hash import kernel_source_hash
+    path = os.path.join(ROOT, "profiles", f"counters_{workload}.json")
+    try:
+        c = json.load(open(path))
+    except Exception:
+        return None, "no committed counters for this workload"
+    if c.get("workload") != workload:
+        return None, "committed counters are for another workload"
+    if c.get("kernel_source_hash") != kernel_source_hash():
+        return None, f"committed counters are stale (measured on kernel sources {c.get('kernel_source_hash')}, running {kernel_source_hash()})"
+    return c, None
+
+
+def exclusive_profile(dxrs_amd, local_rank, stream, spheres, materials, sd, gs, tex, tiled, ex, step_on, args):
+    """the same frames one at a time (one frame in flight, 20 frames): per-launch durations without other frames sharing the GPU"""
+    r1 = dxrs_amd.Renderer(device=local_rank, stream=stream, frames_in_flight=1)
+    r1.set_scene(spheres, materials, sd); r1.set_constants(gs)
+    if tex is not None:
+        r1.set_textures(tex)
+    if tiled:
+        r1.set_partition_ex(*ex.range)
+    for k in range(4):
+        step_on(r1, k)
+    r1.set_profiling(True)
+    for k in range(20):
+        step_on(r1, args.warmup + k)
+    p1 = r1.profile(reset=True)
+    r1.close()
+    return p1
+
+
+def roofline_object(args, w, h, world, tiled, prof, tot_ev, qs, elapsed, elapsed_ev, ms_per_step, n_spheres, exclusive):
+    """`achieved` = algorithmic bytes of the dominant kernel class per launch / its average launch duration (HIP events of
+    this run); algorithmic bytes = 160 B per ray traced + 40 B per path finished by those launches, plus -- for scenes traversed in
+    global memory (C5) -- the scene term from the kernels' own counters: 64 B per node record read + 16 B per sphere record tested."""
+    n_f = args.steps
+    my_pixels = tot_ev.pixels / n_f
+    my_rays = tot_ev.rays / n_f
+    my_secondary = my_rays - my_pixels
+    split = prof.shade_launches > 0
+    workload = f"{args.scene}-{w}x{h}-{args.spp}spp-{args.bounces}b"
+    plain = not (args.di or args.textures or args.env_map or args.animate or tiled)
+    counters, stale = load_counters(workload) if plain else (None, "counters are collected for the plain single-GPU workloads only")
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    if split:
+        # split schedule (BVH in global memory): every ray is traced by a traversal-type launch (primary_kernel, traverse[_dyn]_kernel,
+        # tail_kernel); the class is all of them
+        name, cls = "traversal kernels of the split schedule (primary_kernel + traverse_dyn_kernel + tail_kernel)", ("primary", "traverse", "tail")
+        scene_bytes = 64.0 * tot_ev.node_visits + 16.0 * tot_ev.sphere_tests
+        b = (160.0 * my_rays + 40.0 * tot_ev.paths / n_f) * n_f + scene_bytes
+        ms, n = prof.ms_traverse + prof.ms_tail, prof.traverse_launches + prof.tail_launches
+        out["scene_term"] = {"node_visits_per_ray": tot_ev.node_visits / max(tot_ev.rays, 1), "sphere_tests_per_ray": tot_ev.sphere_tests / max(tot_ev.rays, 1),
+                             "bytes_per_frame": scene_bytes / n_f, "accounting": "64 B per node record read + 16 B per sphere record tested (device counters of the traversal kernels)"}
+        impl = None
+        rays_class = my_rays
+    else:
+        n_wf = prof.traverse_launches // n_f  # compacting passes per frame (incl. the primary pass)
+        inline1 = tot_ev.rays_first_pass_inline / n_f  # bounce-1 rays the primary pass traced in registers (never queued)
+        if qs and len(qs) > n_wf >= 1:
+            wf_in, wf_out, loop_in = sum(qs[1:n_wf]), sum(qs[1:n_wf + 1]), qs[n_wf]
+            px_wf = qs[0] - loop_in if world == 1 else my_pixels - loop_in
+        else:  # no per-queue sizes (spp > 1): every secondary ray is written once and read once
+            wf_in = wf_out = my_secondary; loop_in = 0; px_wf = my_pixels
+        rays_wf = my_pixels + inline1 + wf_in          # compacting passes: primaries, in-register bounce-1 rays, queued rays
+        rays_loop = max(my_rays - rays_wf, 0.0)        # everything else is traced by the looping pass
+        if prof.ms_traverse >= prof.ms_tail:
+            name, cls = "bounce_kernel<primary> (primary / compacting trace+shade passes)", ("bounce<primary>", "bounce<compact>")
+            b, ms, n, rays_class = (160.0 * rays_wf + 40.0 * px_wf * args.spp) * n_f, prof.ms_traverse, prof.traverse_launches, rays_wf
+            impl = (48.0 * wf_in + 48.0 * wf_out + 16.0 * px_wf) * n_f
+        else:
+            name, cls = "bounce_kernel<loop> (looping trace+shade pass)", ("bounce<loop>",)
+            b, ms, n, rays_class = (160.0 * rays_loop + 40.0 * loop_in * args.spp) * n_f, prof.ms_tail, prof.tail_launches, rays_loop
+            impl = (48.0 * loop_in + 16.0 * loop_in) * n_f
+    achieved = (b / n) / (ms / n * 1e-3) / 1e9 if n and ms > 0 else 0.0
+    out.update(kernel=name, achieved=achieved, frac=achieved / HBM_PEAK_GBS, bytes_per_launch=b / max(n, 1), avg_launch_ms=ms / max(n, 1), launches_per_frame=n / n_f,
+               rays_per_launch=rays_class / max(n / n_f, 1),
+               accounting="SURVEY 8(d): 160 B per ray traced + 40 B per path finished by these launches" + (" + the scene term" if split else ""))
+    # measured HBM traffic of the class (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch, committed by profiles/collect.sh)
+    traffic = None
+    if counters:
+        per = [counters["kernels"][k] for k in cls if k in counters["kernels"] and "hbm_bytes_per_launch" in counters["kernels"][k]]
+        if per:
+            traffic = sum(k["hbm_bytes_per_launch"] * k["launches"] for k in per) / sum(k["launches"] for k in per)
+    out["traffic"] = traffic
+    out["counters"] = {"file": f"profiles/counters_{workload}.json", "used": counters is not None, "reason": stale}
+    if impl is not None:
+        out["implementation_bytes_per_launch"] = impl / max(n, 1)  # what this fused implementation has to move: rays kept in registers cost nothing
+    # What actually binds: VALU issue.  gfx950 issues one wave64 VALU instruction per SIMD every 4 cycles, or two in one 4-cycle slot when
+    # they are adjacent, independent and at least one is an fp32 fma / mul / add (profiles/r02_valu_rate.txt, r02_valu_mix.txt); this
+    # branchy scalar code pairs little, so both bounds are given.
+    if counters and all("valu_insts_per_launch" in k for k in counters["kernels"].values()):
+        per_frame = sum(k["valu_insts_per_launch"] * k["launches"] for k in counters["kernels"].values()) / counters["frames_per_pass"]
+        t4, t2 = per_frame * 4 / 1024 / 2.4e9 * 1e3, per_frame * 2 / 1024 / 2.4e9 * 1e3
+        out["valu"] = {"wave_insts_per_frame": per_frame, "bound_ms_unpaired_4_cycles": t4, "bound_ms_fully_paired_2_cycles": t2,
+                       "frac_of_unpaired_bound": t4 / ms_per_step, "frac_of_paired_bound": t2 / ms_per_step,
+                       "wait_fractions": {k: {f: v[f] for f in ("active_frac", "wait_any_frac", "wait_inst_frac") if f in v} for k, v in counters["kernels"].items()},
+                       "source": "SQ_INSTS_VALU per launch (rocprofv3, one frame in flight) x 4 or 2 cycles / 1024 SIMDs / 2.4 GHz"}
+    else:
+        out["valu"] = None
+    out.update(compacting_ms_per_frame=prof.ms_traverse / n_f, shade_ms_per_frame=prof.ms_shade / n_f, loop_ms_per_frame=prof.ms_tail / n_f,
+               ms_per_step_with_events=elapsed_ev / n_f * 1e3, sustained_gbs=(b / n_f) / (elapsed / args.steps) / 1e9)
+    excl = None
+    if args.frames_in_flight > 1 and not split:
+        p1 = exclusive()
+        ms1, n1 = (p1.ms_tail, p1.tail_launches) if "loop" in name else (p1.ms_traverse, p1.traverse_launches)
+        if n1 and ms1 > 0:
+            excl = {"avg_launch_ms": ms1 / n1, "achieved": (b / n) / (ms1 / n1 * 1e-3) / 1e9}
+            excl["frac"] = excl["achieved"] / HBM_PEAK_GBS
+    out["exclusive"] = excl
+    out["note"] = ("bound / achieved / frac follow the measurement contract: NOTIONAL wavefront bytes (SURVEY 8(d)) over the launch duration, not a bandwidth -- "
+                   "'traffic' is the measured HBM bytes per launch (far below: the fused kernels keep rays in registers), 'valu' the instruction-issue bound "
+                   "that binds; with N frames in flight launches of consecutive frames overlap and stretch ('exclusive' = one frame at a time)")
+    return out
 
 
 def init_cabi_gather(r, dist, torch, dev, rank, world):

@@ -101,7 +101,7 @@ class PtStats(C.Structure):
         ("ms_traverse", C.c_double), ("ms_shade", C.c_double), ("traverse_launches", C.c_uint32),
         ("shade_launches", C.c_uint32), ("bytes_algorithmic", C.c_uint64),
         ("ms_tail", C.c_double), ("tail_launches", C.c_uint32), ("beams_used", C.c_uint32),
-        ("rays_first_pass_inline", C.c_uint64),
+        ("rays_first_pass_inline", C.c_uint64), ("node_visits", C.c_uint64), ("sphere_tests", C.c_uint64),
     ]
 
 

@@ -40,7 +40,7 @@ struct EventPair {
 struct Knobs {
     int split = -1, traverse_blocks_per_cu = -1, fused_threads = -1, no_adaptive_grid = -1, shade_blocks_per_cu = -1, tail_threshold = -1,
         tail_blocks_per_cu = -1, loop_threads = -1, inline2_min_slots = -1, tail_after = -1, seg = -1, loop_use_tail = -1, fuse_loop = -1,
-        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1;
+        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1;
 };
 
 // Per-frame-in-flight state (see PtContext::lanes).
@@ -62,7 +62,8 @@ struct Lane {
     uint64_t prev_signature = 0;
     uint32_t* d_seg_counts = nullptr;        // kMaxSegs segment sizes of the primary pass -> looping pass hand-over
     unsigned long long* d_totals = nullptr;  // [0] running secondary-ray total, [1] last folded frame, [2],[3] tail counters,
-                                             // [4] running count of in-register secondary rays of primary passes, [5] unused
+                                             // [4] running count of in-register secondary rays of primary passes, [5] unused,
+                                             // [6] node visits, [7] sphere tests of the global-memory traversal kernels
     // private copy of the moving part of the scene (pt_update_spheres / pt_refit_accel): spheres, Morton-ordered spheres
     // and node boxes; null = this lane renders the context's master scene
     float4* d_sph = nullptr;
@@ -119,6 +120,7 @@ struct PtContext {
 
     // accel
     float4* d_nodes = nullptr;
+    float4* d_wide = nullptr;        // 4-wide view of the tree (global-memory scenes only; null otherwise)
     float4* d_sph_sorted = nullptr;
     uint32_t* d_sorted_id = nullptr;
     uint32_t n_nodes = 0, depth = 0;
@@ -335,18 +337,31 @@ PtStatus validate_frame(PtContext* c)
     return PT_OK;
 }
 
+inline uint32_t knob_or(int v, uint32_t dflt) { return v < 0 ? dflt : (uint32_t)v; }
+
+// per-lane traversal-stack entries: one per level for the binary walk; the wide walk pushes up to three per wide level
+uint32_t stack_entries(const PtContext* c, bool wide)
+{
+    return wide ? std::max(1u, c->depth) + (c->depth + 1u) / 2u + 2u : std::max(1u, c->depth);
+}
+
 SceneView make_scene_view(const PtContext* c, const Lane* L = nullptr)
 {
     SceneView sv{};
     const bool priv = L && L->scene_private;
     sv.nodes = priv ? L->d_nodes : c->d_nodes;
+    sv.wide = priv ? nullptr : c->d_wide;  // (a lane's refitted private tree is walked through its binary records)
     sv.sph_sorted = priv ? L->d_sph_sorted : c->d_sph_sorted;
     sv.sorted_id = c->d_sorted_id;
     sv.sph = priv ? L->d_sph : c->d_sph;
     sv.mats = c->d_mats;
     sv.n = c->n;
     sv.n_nodes = c->n_nodes;
-    sv.stack_depth = std::max(1u, c->depth);
+    sv.stack_depth = stack_entries(c, sv.wide != nullptr);
+    // Global-memory scenes: a lane makes at most this many node visits before its wave turns to the sphere tests.  Unbounded, the
+    // lanes that already hold a leaf idle until the longest descent of the wave ends (hundreds of visits in the 2^20-sphere scene's
+    // heavy tail): 3.99 -> 2.54 ms per frame there with any bound from 2 to 24; LDS-resident scenes (coherent, shallow) gain nothing.
+    sv.descent_cap = c->lds_scene ? 0u : knob_or(c->knobs.descent, 8u);
     sv.lds_scene = c->lds_scene ? 1u : 0u;
     for (int i = 0; i < 4; i++) sv.env[i] = c->sd.EnvironmentLightColor[i];
     if (c->has_textures) { sv.tex = c->d_tex; sv.tex_maps = c->d_tex_maps; sv.rot = (L && L->d_rot && L->rot_gen == c->rot_gen) ? L->d_rot : c->d_rot; }
@@ -388,11 +403,9 @@ Knobs read_knobs()
     k.inline2_min_slots = env_knob("PT_INLINE2_MIN_SLOTS"); k.tail_after = env_knob("PT_TAIL_AFTER"); k.seg = env_knob("PT_SEG");
     k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
     k.dyn_blocks_per_cu = env_knob("PT_DYN_BLOCKS_PER_CU"); k.debug_counts = std::getenv("PT_DEBUG_COUNTS") ? 1 : -1; k.sah = env_knob("PT_SAH");
-    k.sah_max_spheres = env_knob("PT_SAH_MAX_SPHERES"); k.beams = env_knob("PT_BEAMS");
+    k.sah_max_spheres = env_knob("PT_SAH_MAX_SPHERES"); k.beams = env_knob("PT_BEAMS"); k.wide = env_knob("PT_WIDE"); k.descent = env_knob("PT_DESCENT");
     return k;
 }
-
-inline uint32_t knob_or(int v, uint32_t dflt) { return v < 0 ? dflt : (uint32_t)v; }
 
 EventPair* next_events(PtContext* c, int kind)
 {
@@ -535,7 +548,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     // reaches 4) -- measured 4.3 vs 5.3 ms per frame on the 2^20-sphere scene.
     const bool split = (c->flags & PT_FLAG_SPLIT_KERNELS) || knob_or(c->knobs.split, c->lds_scene ? 0u : 1u) != 0;
     // every check that can reject the frame comes before any state change (lane rotation, counter parity, markers)
-    if (traverse_lds_bytes_for(c->n_nodes, c->n, std::max(1u, c->depth), c->lds_scene) > kMaxLdsBytes - 9u * 1024u)  // (the kernels' static LDS comes on top)
+    if (traverse_lds_bytes_for(c->n_nodes, c->n, stack_entries(c, c->d_wide != nullptr), c->lds_scene) > kMaxLdsBytes - 9u * 1024u)  // (the kernels' static LDS comes on top)
         return fail(c, PT_ERR_UNSUPPORTED, "BVH depth needs more traversal-stack LDS than a workgroup can have");
     // frames in flight: this frame runs on the next lane (its own stream and work buffers); the rotation itself happens
     // below, once the lane's buffers exist
@@ -719,7 +732,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
                 const uint32_t items = primary ? pm.n_slots : estimate(k);
                 const uint32_t cap = loop ? tail_cap : trav_cap;
                 if (loop && c->knobs.loop_use_tail >= 0) {
-                    PT_HIP(c, launch_tail(sv, pm, fp, qin, L.scratch, out, counts + k, fc.tail_rays, grid_for(items, kTailThreads, tail_cap), L.stream));
+                    PT_HIP(c, launch_tail(sv, pm, fp, qin, L.scratch, out, counts + k, fc.tail_rays, fc.totals, grid_for(items, kTailThreads, tail_cap), L.stream));
                     break;
                 }
                 PT_HIP(c, bracket(loop ? 3 : (primary ? 0 : 1), [&] {
@@ -741,14 +754,14 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
                 if ((st = poll(k, empty, go_loop)) != PT_OK) return st;
                 if (empty) break;
                 if (go_loop) {
-                    PT_HIP(c, bracket(3, [&] { return launch_tail(sv, pm, fp, qout, L.scratch, out, counts + k + 1, fc.tail_rays, grid_for(estimate(k + 1), kTailThreads, tail_cap), L.stream); }));
+                    PT_HIP(c, bracket(3, [&] { return launch_tail(sv, pm, fp, qout, L.scratch, out, counts + k + 1, fc.tail_rays, fc.totals, grid_for(estimate(k + 1), kTailThreads, tail_cap), L.stream); }));
                     break;
                 }
                 if (!c->lds_scene && sv.n > 1 && knob_or(c->knobs.ray_replacement, 1)) {
                     // persistent waves with ray replacement (heavy-tailed visit counts of large scenes)
                     uint32_t* cursor = counts + L.cap_counts + k + 1;
                     const uint32_t grid = std::min(grid_for(estimate(k + 1), 256u, c->num_cus * 8u), c->num_cus * knob_or(c->knobs.dyn_blocks_per_cu, 6));
-                    PT_HIP(c, bracket(1, [&] { return launch_traverse_dyn(sv, qout, counts + k + 1, cursor, grid, L.stream); }));
+                    PT_HIP(c, bracket(1, [&] { return launch_traverse_dyn(sv, qout, counts + k + 1, cursor, fc.totals, grid, L.stream); }));
                 } else {
                     PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, counts + k + 1, grid_for(estimate(k + 1), trav_threads, trav_cap), L.stream); }));
                 }
@@ -871,9 +884,9 @@ PtStatus pt_create(const PtConfig* config, PtContext** out_ctx)
         bool ok = true;
         for (auto& e : L.ev_poll) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         if (!ok || hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) != hipSuccess
-            || hipMalloc(&L.d_totals, 6 * sizeof(unsigned long long)) != hipSuccess
+            || hipMalloc(&L.d_totals, 8 * sizeof(unsigned long long)) != hipSuccess
             || hipMalloc(&L.d_seg_counts, kMaxSegs * sizeof(uint32_t)) != hipSuccess
-            || hipMemsetAsync(L.d_totals, 0, 6 * sizeof(unsigned long long), L.stream) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
+            || hipMemsetAsync(L.d_totals, 0, 8 * sizeof(unsigned long long), L.stream) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
     }
     *out_ctx = c;
     return PT_OK;
@@ -900,7 +913,7 @@ void pt_destroy(PtContext* c)
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);
         if (L.stream && L.stream != c->stream) (void)hipStreamDestroy(L.stream);
     }
-    free_dev(c->d_sph); free_dev(c->d_mats); free_dev(c->d_nodes); free_dev(c->d_sph_sorted); free_dev(c->d_sorted_id); free_dev(c->d_lights);
+    free_dev(c->d_sph); free_dev(c->d_mats); free_dev(c->d_nodes); free_dev(c->d_wide); free_dev(c->d_sph_sorted); free_dev(c->d_sorted_id); free_dev(c->d_lights);
     free_dev(c->beam.d_lists);
     if (c->beam.ev_ready) (void)hipEventDestroy(c->beam.ev_ready);
     if (c->beam.ev_last_use) (void)hipEventDestroy(c->beam.ev_last_use);
@@ -1029,6 +1042,14 @@ PtStatus pt_build_accel(PtContext* c, PtAccelInfo* info)
     const uint32_t scene_bytes = traverse_lds_bytes_for(c->n_nodes, n, 0, true);
     c->lds_scene = !(c->flags & PT_FLAG_NO_LDS_SCENE) && scene_bytes <= kLdsSceneBudget
                    && traverse_lds_bytes_for(c->n_nodes, n, std::max(1u, c->depth), true) <= kMaxLdsBytes / 2;
+    // Scenes that traverse global memory get the 4-wide view of the tree: half the dependent node fetches per ray (the bound of
+    // the 2^20-sphere scene).  PT_WIDE=0 keeps the binary walk, for A/B runs.
+    free_dev(c->d_wide);
+    if (!c->lds_scene && c->n_nodes > 1 && knob_or(c->knobs.wide, 1u) != 0) {
+        PT_HIP(c, hipMalloc(&c->d_wide, (size_t)c->n_nodes * 4u * sizeof(float4)));
+        PT_HIP(c, lbvh_gpu_collapse4(reinterpret_cast<const PtBvhNode*>(c->d_nodes), c->n_nodes, c->d_wide, c->stream));
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+    }
     c->accel_valid = true;
     c->scene_gen++;
     if (info) {
@@ -1471,22 +1492,26 @@ PtStatus pt_get_totals(PtContext* c, PtStats* totals, int reset)
     if (!c) return PT_ERR_INVALID_ARG;
     if (!totals) return fail(c, PT_ERR_INVALID_ARG, "pt_get_totals: null output");
     PT_HIP(c, hipSetDevice(c->device));
-    unsigned long long secondary = 0, first_pass = 0;
+    unsigned long long secondary = 0, first_pass = 0, node_visits = 0, sphere_tests = 0;
     for (uint32_t i = 0; i < c->n_lanes; i++) {
         Lane& L = c->lanes[i];
-        unsigned long long s[5] = {};
+        unsigned long long s[8] = {};
         PT_HIP(c, flush_all_counters(L));  // fold the frames still sitting in the per-frame counters
         PT_HIP(c, hipMemcpyAsync(s, L.d_totals, sizeof s, hipMemcpyDeviceToHost, L.stream));
         PT_HIP(c, hipStreamSynchronize(L.stream));
         secondary += s[0];
         first_pass += s[4];
+        node_visits += s[6];
+        sphere_tests += s[7];
         if (reset) {
             PT_HIP(c, hipMemsetAsync(L.d_totals, 0, 2 * sizeof(unsigned long long), L.stream));
-            PT_HIP(c, hipMemsetAsync(L.d_totals + 4, 0, sizeof(unsigned long long), L.stream));
+            PT_HIP(c, hipMemsetAsync(L.d_totals + 4, 0, 4 * sizeof(unsigned long long), L.stream));
         }
     }
     std::memset(totals, 0, sizeof *totals);
     totals->rays_first_pass_inline = first_pass;
+    totals->node_visits = node_visits;
+    totals->sphere_tests = sphere_tests;
     totals->rays = c->tot_pixels + secondary;
     totals->paths = c->tot_paths;
     totals->pixels = c->tot_pixels;

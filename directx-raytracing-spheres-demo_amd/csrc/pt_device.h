@@ -35,6 +35,7 @@ constexpr uint32_t kMissId = 0xFFFFFFFFu;
 //   n0 = lo0.xyz, hi0.x   n1 = hi0.yz, lo1.xy   n2 = lo1.z, hi1.xyz   n3 = child0, child1, parent, pad (ints)
 struct SceneView {
     const float4* nodes;        // n_nodes * 4
+    const float4* wide;         // 4-wide quantised view of the tree (n_nodes * 4, pt_lbvh_gpu.hip collapse4_kernel) or null; global-memory scenes
     const float4* sph_sorted;   // Morton order {cx,cy,cz,r}
     const uint32_t* sorted_id;  // Morton order -> original sphere id
     const float4* sph;          // original order (shade)
@@ -42,6 +43,7 @@ struct SceneView {
     uint32_t n;                 // spheres
     uint32_t n_nodes;           // internal nodes (n - 1; 0 when n == 1)
     uint32_t stack_depth;       // traversal stack entries per lane
+    uint32_t descent_cap;       // global-memory scenes: node visits per lane before the wave turns to its sphere tests (0 = unbounded)
     uint32_t lds_scene;         // 1: kernels stage nodes + sph_sorted + sorted_id in LDS
     float env[4];               // SceneData.EnvironmentLightColor
     // row N1 (textured spheres); null when the scene has no textures

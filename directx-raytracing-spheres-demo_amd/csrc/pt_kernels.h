@@ -22,13 +22,14 @@ hipError_t launch_primary(const SceneView& sv, const PixelMap& pm, const FramePa
 // primary beams: per-8x8-block candidate sphere lists for the primary pass (lists: pm.n_slots / 64 records of 16 dwords)
 hipError_t launch_beams(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, uint32_t* lists, hipStream_t stream);
 hipError_t launch_traverse(const SceneView& sv, const RayQueue& q, const uint32_t* count_ptr, uint32_t grid, hipStream_t stream);
-hipError_t launch_traverse_dyn(const SceneView& sv, const RayQueue& q, const uint32_t* count_ptr, uint32_t* cursor, uint32_t grid, hipStream_t stream);
+hipError_t launch_traverse_dyn(const SceneView& sv, const RayQueue& q, const uint32_t* count_ptr, uint32_t* cursor, unsigned long long* totals, uint32_t grid,
+                               hipStream_t stream);
 hipError_t launch_shade(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const RayQueue& qout,
                         const Scratch& scratch, float4* out, const uint32_t* count_in, uint32_t* count_out, uint32_t grid, hipStream_t stream);
 hipError_t launch_trace(const SceneView& sv, const float* o, const float* d, uint32_t n_rays, float tmin, int use_bvh, float* out_t,
                         uint32_t* out_id, uint2* out_visits, hipStream_t stream);
 hipError_t launch_tail(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const Scratch& scratch, float4* out,
-                       const uint32_t* count_ptr, unsigned long long* tail_rays, uint32_t grid, hipStream_t stream);
+                       const uint32_t* count_ptr, unsigned long long* tail_rays, unsigned long long* totals, uint32_t grid, hipStream_t stream);
 hipError_t launch_flush_counters(uint32_t* counts, uint32_t n_counts, unsigned long long* tail, unsigned long long* totals, uint32_t* host_counts,
                                  hipStream_t stream);
 hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const RayQueue& qout,

@@ -108,15 +108,65 @@ __device__ __forceinline__ int stack_decode(uint32_t v) { return (int)v; }
 
 constexpr int kTraversalDone = (int)0x80000000;  // not a valid leaf code (leaf codes are >= -2^30)
 
+// One visit of a 4-wide node (pt_lbvh_gpu.hip collapse4_kernel: the grandchildren of an even-depth binary node, their boxes as
+// 8-bit offsets on a per-node power-of-two grid; global-memory scenes): four slab tests from ONE 64-byte record, the hit
+// children ordered near to far by a 5-exchange network, the nearest descended into, the others pushed far-first.  Half the
+// dependent fetches AND half the sectors per ray of the binary walk (DESIGN.md "Wide nodes").  A plane's ray parameter is
+// t = fma(byte, cell * (1/d), fma(origin, 1/d, -o/d)): the decode fma(byte, cell, origin) folded into the slab test.
+// Sets node = kTraversalDone when nothing is left.
+template <typename StackT>
+__device__ __forceinline__ void wide_visit(const float4* __restrict__ wide, int& node, uint32_t& sp, StackT* stack, uint32_t stride, float ix, float iy,
+                                           float iz, float ox, float oy, float oz, float tmin, float best)
+{
+    const uint4* __restrict__ w = reinterpret_cast<const uint4*>(wide) + (size_t)node * 4u;
+    const uint4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    const float sx = as_float((w0.w & 0xFFu) << 23) * ix, sy = as_float(((w0.w >> 8) & 0xFFu) << 23) * iy, sz = as_float(((w0.w >> 16) & 0xFFu) << 23) * iz;
+    const float bx0 = pt_fma(as_float(w0.x), ix, ox), by0 = pt_fma(as_float(w0.y), iy, oy), bz0 = pt_fma(as_float(w0.z), iz, oz);
+    float tn[4];
+    int ref[4] = { (int)w2.z, (int)w2.w, (int)w3.x, (int)w3.y };
+#define PT_WIDE_CHILD(c)                                                                                                 \
+    {                                                                                                                    \
+        const float ax = pt_fma((float)((w1.x >> (8 * c)) & 0xFFu), sx, bx0), bx = pt_fma((float)((w1.w >> (8 * c)) & 0xFFu), sx, bx0);   \
+        const float ay = pt_fma((float)((w1.y >> (8 * c)) & 0xFFu), sy, by0), by = pt_fma((float)((w2.x >> (8 * c)) & 0xFFu), sy, by0);   \
+        const float az = pt_fma((float)((w1.z >> (8 * c)) & 0xFFu), sz, bz0), bz = pt_fma((float)((w2.y >> (8 * c)) & 0xFFu), sz, bz0);   \
+        const float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));                      \
+        const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));                       \
+        tn[c] = (tnear <= tfar && ref[c] != kTraversalDone) ? tnear : kInf;                                             \
+    }
+    PT_WIDE_CHILD(0) PT_WIDE_CHILD(1) PT_WIDE_CHILD(2) PT_WIDE_CHILD(3)
+#undef PT_WIDE_CHILD
+#define PT_WIDE_CSWAP(a, b)                                                                                              \
+    {                                                                                                                    \
+        const bool sw = tn[b] < tn[a];                                                                                   \
+        const float ta = sw ? tn[b] : tn[a], tb = sw ? tn[a] : tn[b];                                                    \
+        const int ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];                                                  \
+        tn[a] = ta; tn[b] = tb; ref[a] = ra; ref[b] = rb;                                                                \
+    }
+    PT_WIDE_CSWAP(0, 1) PT_WIDE_CSWAP(2, 3) PT_WIDE_CSWAP(0, 2) PT_WIDE_CSWAP(1, 3) PT_WIDE_CSWAP(1, 2)
+#undef PT_WIDE_CSWAP
+    if (tn[3] < kInf) { stack[sp] = stack_encode<StackT>(ref[3]); sp += stride; }
+    if (tn[2] < kInf) { stack[sp] = stack_encode<StackT>(ref[2]); sp += stride; }
+    if (tn[1] < kInf) { stack[sp] = stack_encode<StackT>(ref[1]); sp += stride; }
+    if (tn[0] < kInf) {
+        node = ref[0];
+    } else if (sp == 0) {
+        node = kTraversalDone;
+    } else {
+        sp -= stride;
+        node = stack_decode(stack[sp]);
+    }
+}
+
 // Closest hit over the LBVH ("while-while" traversal: descend internal nodes until every lane of the wave holds a
 // leaf or has finished, then run the sphere tests together).  nodes/sph/ids may live in LDS or global memory (the
 // address space is inferred after inlining).  stack: per-lane stack, entry e of lane l at stack[e * stride + l].
 // The result is identical to brute force: nearest t, ties -> lowest original id (leaf boxes are padded so the slab
 // test is conservative w.r.t. intersect_sphere; culling is <=).
-template <typename StackT, bool kCount = false>
+// kWide: `nodes` is the 4-wide view of the tree (128-byte records, wide_visit) instead of the binary records.
+template <typename StackT, bool kCount = false, bool kWide = false>
 __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, const float4* __restrict__ sph,
                                             const uint32_t* __restrict__ ids, uint32_t n, f3 o, f3 d, float tmin, float tmax,
-                                            StackT* stack, uint32_t stride, float& t_out, uint32_t& id_out, uint32_t* visits = nullptr)
+                                            StackT* stack, uint32_t stride, float& t_out, uint32_t& id_out, uint32_t* visits = nullptr, uint32_t descent_cap = 0)
 {
     uint32_t n_nodes_visited = 0, n_spheres_tested = 0;  // kCount only (pt_trace_rays statistics hook)
     float best = tmax;
@@ -133,8 +183,12 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
     int node = 0;
     uint32_t sp = 0;  // stack offset in elements: a multiple of `stride` (entry e of this lane lives at stack[e * stride])
     for (;;) {
+        // descent_cap > 0 bounds the node visits a lane makes before the wave turns to the sphere tests (incoherent rays in big
+        // scenes: lanes that already hold a leaf otherwise idle until the longest descent of the wave ends); 0 = unbounded
+        uint32_t budget = descent_cap;
         while (node >= 0) {
             if (kCount) n_nodes_visited++;
+            if (kWide) { wide_visit<StackT>(nodes, node, sp, stack, stride, ix, iy, iz, ox, oy, oz, tmin, best); if (--budget == 0u) break; continue; }
             const float4 n0 = nodes[node * 4 + 0];
             const float4 n1 = nodes[node * 4 + 1];
             const float4 n2 = nodes[node * 4 + 2];
@@ -168,8 +222,10 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
                 sp -= stride;
                 node = stack_decode(stack[sp]);
             }
+            if (--budget == 0u) break;
         }
         if (node == kTraversalDone) break;
+        if (node >= 0) continue;  // the budget ran out mid-descent
         {
             if (kCount) n_spheres_tested++;
             const uint32_t k = ~(uint32_t)node;
@@ -186,7 +242,32 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
     }
     // t < tmax is required by intersect_sphere's contract: best starts at tmax and only shrinks
     t_out = best; id_out = best_id;
-    if (kCount && visits) { visits[0] = n_nodes_visited; visits[1] = n_spheres_tested; }
+    if (kCount && visits) { visits[0] += n_nodes_visited; visits[1] += n_spheres_tested; }
+}
+
+// closest_hit through whichever view of the tree the scene offers: the LDS copy (binary records) when kLds, else the 4-wide view
+// when the scene has one (SceneView::wide), else the binary records in global memory
+template <bool kLds, typename StackT>
+__device__ __forceinline__ void closest_hit_any(const SceneView& sv, const float4* __restrict__ nodes, const float4* __restrict__ sph,
+                                                const uint32_t* __restrict__ ids, f3 o, f3 d, float tmin, float tmax, StackT* stack, uint32_t stride,
+                                                float& t_out, uint32_t& id_out, uint32_t* visits = nullptr)
+{
+    // visits (global-memory scenes): this lane's running {node visits, sphere tests}, the scene term of SURVEY 8(d)'s byte accounting
+    if (!kLds && visits) {
+        if (sv.wide) closest_hit<StackT, true, true>(sv.wide, sph, ids, sv.n, o, d, tmin, tmax, stack, stride, t_out, id_out, visits, sv.descent_cap);
+        else closest_hit<StackT, true>(nodes, sph, ids, sv.n, o, d, tmin, tmax, stack, stride, t_out, id_out, visits, sv.descent_cap);
+    } else if (!kLds && sv.wide) {
+        closest_hit<StackT, false, true>(sv.wide, sph, ids, sv.n, o, d, tmin, tmax, stack, stride, t_out, id_out, nullptr, sv.descent_cap);
+    } else {
+        closest_hit<StackT>(nodes, sph, ids, sv.n, o, d, tmin, tmax, stack, stride, t_out, id_out, nullptr, sv.descent_cap);
+    }
+}
+
+// adds a workgroup's {node visits, sphere tests} to the lane's running totals (two atomics per workgroup)
+__device__ __forceinline__ void flush_visit_counters(unsigned long long* totals, const uint32_t v[2])
+{
+    block_atomic_add(totals + 6, v[0]);
+    block_atomic_add(totals + 7, v[1]);
 }
 
 // ------------------------------------------------------------------------------------------------ primary beams
@@ -352,6 +433,7 @@ __global__ __launch_bounds__(kTraverseThreads) void primary_kernel(SceneView sv,
         stack = reinterpret_cast<StackT*>(smem);
     }
     stack += threadIdx.x;
+    uint32_t visits[2] = { 0u, 0u };
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < pm.n_slots; slot += gridDim.x * blockDim.x) {
         const PixelRef pr = slot_to_pixel(pm, slot);
         f3 o = make_f3(0, 0, 0), d = make_f3(0, 0, 1);
@@ -362,7 +444,7 @@ __global__ __launch_bounds__(kTraverseThreads) void primary_kernel(SceneView sv,
             float tmin, tmax;
             primary_ray(fp.cam, pr.px, pr.py, o, d, tmin, tmax);
             rng = rng_init(pr.px, pr.py, fp.frame_index);
-            closest_hit<StackT>(nodes, sph, ids, sv.n, o, d, tmin, tmax, stack, blockDim.x, t, id);
+            closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, o, d, tmin, tmax, stack, blockDim.x, t, id, kLds ? nullptr : visits);
         } else if (pm.mode == 1) {
             // padding pixel of an edge tile (or a tile past the end): defined as zero
             // (out_index is always inside the packed buffer in tile mode)
@@ -375,6 +457,7 @@ __global__ __launch_bounds__(kTraverseThreads) void primary_kernel(SceneView sv,
         q.hit[slot] = make_uint2(as_uint(t), id);
         if (fp.spp > 1) scratch.primary_hit[slot] = make_uint2(as_uint(t), id);
     }
+    if (!kLds) flush_visit_counters(fc.totals, visits);
 }
 
 // ------------------------------------------------------------------------------------------------ traverse
@@ -403,7 +486,7 @@ __global__ __launch_bounds__(kTraverseThreads) void traverse_kernel(SceneView sv
         const float4 b = q.q1[i];
         float t;
         uint32_t id;
-        closest_hit<StackT>(nodes, sph, ids, sv.n, make_f3(a.x, a.y, a.z), make_f3(b.x, b.y, b.z), 0.0f, kInf, stack, blockDim.x, t, id);
+        closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, make_f3(a.x, a.y, a.z), make_f3(b.x, b.y, b.z), 0.0f, kInf, stack, blockDim.x, t, id);
         q.hit[i] = make_uint2(as_uint(t), id);
     }
 }
@@ -414,14 +497,16 @@ __global__ __launch_bounds__(kTraverseThreads) void traverse_kernel(SceneView sv
 // lane that finishes its ray is handed a new one as soon as fewer than kRefillBelow lanes of its wave are busy.
 constexpr uint32_t kRefillBelow = 44;
 
-template <typename StackT>
-__global__ __launch_bounds__(256) void traverse_dyn_kernel(SceneView sv, RayQueue q, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ cursor)
+template <typename StackT, bool kWide>
+__global__ __launch_bounds__(256) void traverse_dyn_kernel(SceneView sv, RayQueue q, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ cursor,
+                                                           unsigned long long* __restrict__ totals)
 {
+    uint32_t visits[2] = { 0u, 0u };  // {node visits, sphere tests} of this lane: the scene term of SURVEY 8(d)'s byte accounting
     extern __shared__ float4 smem[];
     StackT* stack = reinterpret_cast<StackT*>(smem) + threadIdx.x;
     const uint32_t stride = blockDim.x;
     const uint32_t count = *count_ptr;
-    const float4* __restrict__ nodes = sv.nodes;
+    const float4* __restrict__ nodes = kWide ? sv.wide : sv.nodes;
     const float4* __restrict__ sph = sv.sph_sorted;
     const uint32_t* __restrict__ ids = sv.sorted_id;
     const uint32_t lane = lane_id();
@@ -453,7 +538,10 @@ __global__ __launch_bounds__(256) void traverse_dyn_kernel(SceneView sv, RayQueu
         if (!__ballot(active)) break;
         bool finished = false;
         if (active) {
+            uint32_t budget = sv.descent_cap;
             while (node >= 0) {
+                visits[0]++;
+                if (kWide) { wide_visit<StackT>(nodes, node, sp, stack, stride, ix, iy, iz, ox, oy, oz, 0.0f, best); if (--budget == 0u) break; continue; }
                 const float4 n0 = nodes[node * 4 + 0];
                 const float4 n1 = nodes[node * 4 + 1];
                 const float4 n2 = nodes[node * 4 + 2];
@@ -485,10 +573,12 @@ __global__ __launch_bounds__(256) void traverse_dyn_kernel(SceneView sv, RayQueu
                     sp -= stride;
                     node = stack_decode(stack[sp]);
                 }
+                if (--budget == 0u) break;
             }
             if (node == kTraversalDone) {
                 finished = true;
-            } else {
+            } else if (node < 0) {
+                visits[1]++;
                 const uint32_t k = ~(uint32_t)node;
                 const float4 s = sph[k];
                 float t;
@@ -505,6 +595,7 @@ __global__ __launch_bounds__(256) void traverse_dyn_kernel(SceneView sv, RayQueu
             active = false;
         }
     }
+    flush_visit_counters(totals, visits);
 }
 
 // ------------------------------------------------------------------------------------------------ shade
@@ -807,11 +898,12 @@ __global__ __launch_bounds__(kShadeThreads) void shade_kernel(SceneView sv, Pixe
 template <bool kLds, typename StackT, bool kTex>
 __global__ __launch_bounds__(kTailThreads) void tail_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue qin, Scratch scratch,
                                                             float4* __restrict__ out, const uint32_t* __restrict__ count_ptr,
-                                                            unsigned long long* __restrict__ tail_rays)
+                                                            unsigned long long* __restrict__ tail_rays, unsigned long long* __restrict__ totals)
 {
     extern __shared__ float4 smem[];
     const uint32_t count = *count_ptr;
     if (blockIdx.x * blockDim.x >= count) return;
+    uint32_t visits[2] = { 0u, 0u };
     const float4* nodes = sv.nodes;
     const float4* sph = sv.sph_sorted;
     const uint32_t* ids = sv.sorted_id;
@@ -833,12 +925,13 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(SceneView sv, PixelM
         for (;;) {
             float t;
             uint32_t id;
-            closest_hit<StackT>(nodes, sph, ids, sv.n, ps.o, ps.d, 0.0f, kInf, stack, blockDim.x, t, id);
+            closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, ps.o, ps.d, 0.0f, kInf, stack, blockDim.x, t, id, kLds ? nullptr : visits);
             if (!shade_step<true, kTex>(sv, pm, fp, scratch, out, ps, t, id)) break;
             my_rays++;  // rays spawned inside the tail (the input queue's rays are already in counts[])
         }
     }
     block_atomic_add(tail_rays, my_rays);
+    if (!kLds) flush_visit_counters(totals, visits);
 }
 
 // static LDS of the kernels below (counters, the segment prefix table of the looping pass) on top of their dynamic LDS: the
@@ -993,13 +1086,13 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
                         closest_hit_list(sv, beam_rec, beam_count, ps.o, ps.d, tmin, tmax, t, id);
                         if (kMulti) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
                     } else {
-                        closest_hit<StackT>(nodes, sph, ids, sv.n, ps.o, ps.d, tmin, tmax, stack, blockDim.x, t, id);
+                        closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, ps.o, ps.d, tmin, tmax, stack, blockDim.x, t, id);
                         if (kMulti && kPrimary && primary_trace) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
                     }
                     primary_trace = false;
                     if (kDI)  // row N4: the first shading of the primary surface also makes its direct-illumination estimate
                         emit = shade_step<kMulti, kTex, true>(sv, pm, fp, scratch, out, ps, t, id,
-                                                              [&](f3 so, f3 sd, float& t2, uint32_t& id2) { closest_hit<StackT>(nodes, sph, ids, sv.n, so, sd, 0.0f, kInf, stack, blockDim.x, t2, id2); },
+                                                              [&](f3 so, f3 sd, float& t2, uint32_t& id2) { closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, so, sd, 0.0f, kInf, stack, blockDim.x, t2, id2); },
                                                               &my_rays);
                     else
                         emit = shade_step<kMulti, kTex>(sv, pm, fp, scratch, out, ps, t, id);
@@ -1062,7 +1155,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
                     for (;;) {
                         float t;
                         uint32_t id;
-                        closest_hit<StackT>(nodes, sph, ids, sv.n, ps.o, ps.d, 0.0f, kInf, stack, blockDim.x, t, id);
+                        closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, ps.o, ps.d, 0.0f, kInf, stack, blockDim.x, t, id);
                         if (!shade_step<kMulti, kTex>(sv, pm, fp, scratch, out, ps, t, id)) break;
                         my_loop_rays++;
                     }
@@ -1126,14 +1219,14 @@ __global__ __launch_bounds__(kTraverseThreads) void di_kernel(SceneView sv, Pixe
             float tmin, tmax, t;
             uint32_t id;
             primary_ray(fp.cam, pr.px, pr.py, o, d, tmin, tmax);
-            closest_hit<StackT>(nodes, sph, ids, sv.n, o, d, tmin, tmax, stack, blockDim.x, t, id);
+            closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, o, d, tmin, tmax, stack, blockDim.x, t, id);
             // THE primary trace of this frame: the primary pass that follows reads the hit instead of tracing again (as the
             // reference's RTXDI passes and Raytracing.hlsl both start from the G-buffer); it is counted there (queue 0)
             primary_hit[slot] = make_uint2(as_uint(t), id);
             if (id != kMissId) {
                 const HitMaterial hm = hit_material<kTex>(sv, id, o, d, t, true);
                 est = di_estimate<kTex>(sv, fp, pr.px, pr.py, id, d, hm,
-                                        [&](f3 so, f3 sd, float& t2, uint32_t& id2) { closest_hit<StackT>(nodes, sph, ids, sv.n, so, sd, 0.0f, kInf, stack, blockDim.x, t2, id2); },
+                                        [&](f3 so, f3 sd, float& t2, uint32_t& id2) { closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, so, sd, 0.0f, kInf, stack, blockDim.x, t2, id2); },
                                         my_rays);
             }
         }
@@ -1168,10 +1261,14 @@ __global__ __launch_bounds__(kTraverseThreads) void trace_kernel(SceneView sv, c
         uint32_t id;
         uint32_t v[2] = { 0, 0 };
         if (out_visits)
+            if (!kLds && sv.wide)
+                closest_hit<StackT, true, true>(sv.wide, sph, ids, sv.n, make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
+                                                tmin, kInf, stack, blockDim.x, t, id, v);
+            else
             closest_hit<StackT, true>(nodes, sph, ids, sv.n, make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
                                       tmin, kInf, stack, blockDim.x, t, id, v);
         else
-            closest_hit<StackT>(nodes, sph, ids, sv.n, make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
+            closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
                                 tmin, kInf, stack, blockDim.x, t, id);
         out_t[i] = t;
         out_id[i] = id;
@@ -1308,12 +1405,23 @@ hipError_t launch_traverse(const SceneView& sv, const RayQueue& q, const uint32_
     return hipGetLastError();
 }
 
-hipError_t launch_traverse_dyn(const SceneView& sv, const RayQueue& q, const uint32_t* count_ptr, uint32_t* cursor, uint32_t grid, hipStream_t stream)
+hipError_t launch_traverse_dyn(const SceneView& sv, const RayQueue& q, const uint32_t* count_ptr, uint32_t* cursor, unsigned long long* totals, uint32_t grid,
+                               hipStream_t stream)
 {
     const bool small = sv.n_nodes < 32767u;
     const uint32_t lds = 256u * sv.stack_depth * (small ? 2u : 4u);
-    if (small) hipLaunchKernelGGL((traverse_dyn_kernel<uint16_t>), dim3(grid), dim3(256), lds, stream, sv, q, count_ptr, cursor);
-    else hipLaunchKernelGGL((traverse_dyn_kernel<uint32_t>), dim3(grid), dim3(256), lds, stream, sv, q, count_ptr, cursor);
+    if (lds + kStaticLdsMargin > 65536u) {
+        const void* fn = sv.wide ? (small ? (const void*)traverse_dyn_kernel<uint16_t, true> : (const void*)traverse_dyn_kernel<uint32_t, true>)
+                                 : (small ? (const void*)traverse_dyn_kernel<uint16_t, false> : (const void*)traverse_dyn_kernel<uint32_t, false>);
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (sv.wide) {
+        if (small) hipLaunchKernelGGL((traverse_dyn_kernel<uint16_t, true>), dim3(grid), dim3(256), lds, stream, sv, q, count_ptr, cursor, totals);
+        else hipLaunchKernelGGL((traverse_dyn_kernel<uint32_t, true>), dim3(grid), dim3(256), lds, stream, sv, q, count_ptr, cursor, totals);
+    } else {
+        if (small) hipLaunchKernelGGL((traverse_dyn_kernel<uint16_t, false>), dim3(grid), dim3(256), lds, stream, sv, q, count_ptr, cursor, totals);
+        else hipLaunchKernelGGL((traverse_dyn_kernel<uint32_t, false>), dim3(grid), dim3(256), lds, stream, sv, q, count_ptr, cursor, totals);
+    }
     return hipGetLastError();
 }
 
@@ -1330,7 +1438,7 @@ hipError_t launch_beams(const SceneView& sv, const PixelMap& pm, const FramePara
 }
 
 hipError_t launch_tail(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& qin, const Scratch& scratch, float4* out,
-                       const uint32_t* count_ptr, unsigned long long* tail_rays, uint32_t grid, hipStream_t stream)
+                       const uint32_t* count_ptr, unsigned long long* tail_rays, unsigned long long* totals, uint32_t grid, hipStream_t stream)
 {
     const bool small = sv.n_nodes < 32767u;
     const uint32_t elem = small ? 2u : 4u;
@@ -1338,7 +1446,7 @@ hipError_t launch_tail(const SceneView& sv, const PixelMap& pm, const FrameParam
 #define PT_TAIL2(L, T, X)                                                                                                  \
     do {                                                                                                                    \
         if (lds + kStaticLdsMargin > 65536u) (void)hipFuncSetAttribute((const void*)tail_kernel<L, T, X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((tail_kernel<L, T, X>), dim3(grid), dim3(kTailThreads), lds, stream, sv, pm, fp, qin, scratch, out, count_ptr, tail_rays); \
+        hipLaunchKernelGGL((tail_kernel<L, T, X>), dim3(grid), dim3(kTailThreads), lds, stream, sv, pm, fp, qin, scratch, out, count_ptr, tail_rays, totals); \
     } while (0)
 #define PT_TAIL(L, T) do { if (sv.tex_maps) PT_TAIL2(L, T, true); else PT_TAIL2(L, T, false); } while (0)
     if (sv.lds_scene) { if (small) PT_TAIL(true, uint16_t); else PT_TAIL(true, uint32_t); }

@@ -453,4 +453,93 @@ hipError_t lbvh_gpu_refit(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode
     return hipGetLastError();
 }
 
+// ---- 4-wide, quantised view of the binary tree (global-memory scenes; DESIGN.md "Wide nodes") ------------------------------------
+// A binary node at EVEN depth becomes a wide node whose children are its grandchildren (a leaf child stays as it is): the
+// odd-depth nodes are absorbed, every second level of dependent fetches disappears -- and the four child boxes are stored as 8-bit
+// offsets on a per-node power-of-two grid, so a visit reads ONE 64-byte sector (the binary walk reads one per level: half the
+// sectors per ray, which is what bounds the 2^20-sphere scene).  Wide node i lives at index i of its own array (only even-depth
+// slots are used), 16 dwords:
+//   [0..2] grid origin (the union box's lower corner)   [3] three biased exponents (x | y << 8 | z << 16): cell = 2^(e - 127)
+//   [4..6] lower x / y / z plane of children 0..3, one byte each   [7..9] upper planes   [10..13] child references (>= 0: wide
+//   node index, < 0: leaf ~k, 0x80000000: empty)   [14..15] unused
+// A plane decodes as fma(byte, cell, origin) -- the very expression the builder checks here, on the same hardware: lower planes
+// are rounded down and upper planes up until the decoded box contains the binary record's box, so conservativeness carries over.
+constexpr int kEmptyChild = (int)0x80000000;
+
+__device__ __forceinline__ float wide_cell(float extent, uint32_t& biased_exp)
+{
+    // smallest power of two c with 254 * c >= extent (one step of headroom for the outward rounding below)
+    int e = 0;
+    const float m = frexpf(extent * (1.0f / 254.0f), &e);  // extent / 254 = m * 2^e, m in [0.5, 1)
+    (void)m;
+    if (!(extent > 0.0f)) e = -100;
+    if (e < -120) e = -120;
+    biased_exp = (uint32_t)(e + 127);
+    return __uint_as_float(biased_exp << 23);
+}
+
+__global__ void collapse4_kernel(const PtBvhNode* __restrict__ nodes, uint32_t n_nodes, uint4* __restrict__ wide)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += gridDim.x * blockDim.x) {
+        uint32_t depth = 0;
+        for (int p = nodes[i].parent; p >= 0; p = nodes[p].parent) depth++;
+        if (depth & 1u) continue;
+        float lo[4][3], hi[4][3];
+        int ref[4];
+        int k = 0;
+        auto put = [&](const float* l, const float* h, int c) {
+            for (int a = 0; a < 3; a++) { lo[k][a] = l[a]; hi[k][a] = h[a]; }
+            ref[k++] = c;
+        };
+        const PtBvhNode nd = nodes[i];
+        const int cs[2] = { nd.child0, nd.child1 };
+        for (int side = 0; side < 2; side++) {
+            const int c = cs[side];
+            if (c < 0) {
+                put(side ? nd.lo1 : nd.lo0, side ? nd.hi1 : nd.hi0, c);
+            } else {  // odd-depth internal child: absorbed
+                const PtBvhNode ch = nodes[c];
+                put(ch.lo0, ch.hi0, ch.child0);
+                put(ch.lo1, ch.hi1, ch.child1);
+            }
+        }
+        const int n_children = k;
+        float origin[3], cell[3];
+        uint32_t exps = 0, planes[6] = { 0, 0, 0, 0, 0, 0 };
+        for (int a = 0; a < 3; a++) {
+            float mn = lo[0][a], mx = hi[0][a];
+            for (int c = 1; c < n_children; c++) { mn = fminf(mn, lo[c][a]); mx = fmaxf(mx, hi[c][a]); }
+            origin[a] = mn;
+            uint32_t be;
+            cell[a] = wide_cell(mx - mn, be);
+            exps |= be << (8 * a);
+            const float inv = 1.0f / cell[a];  // exact: a power of two
+            for (int c = 0; c < n_children; c++) {
+                int ql = (int)floorf((lo[c][a] - mn) * inv), qh = (int)ceilf((hi[c][a] - mn) * inv);
+                ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+                qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+                while (ql > 0 && __fmaf_rn((float)ql, cell[a], mn) > lo[c][a]) ql--;
+                while (qh < 255 && __fmaf_rn((float)qh, cell[a], mn) < hi[c][a]) qh++;
+                planes[a] |= (uint32_t)ql << (8 * c);
+                planes[3 + a] |= (uint32_t)qh << (8 * c);
+            }
+        }
+        for (int c = n_children; c < 4; c++) ref[c] = kEmptyChild;
+        uint4* w = wide + (size_t)i * 4u;
+        w[0] = make_uint4(__float_as_uint(origin[0]), __float_as_uint(origin[1]), __float_as_uint(origin[2]), exps);
+        w[1] = make_uint4(planes[0], planes[1], planes[2], planes[3]);
+        w[2] = make_uint4(planes[4], planes[5], (uint32_t)ref[0], (uint32_t)ref[1]);
+        w[3] = make_uint4((uint32_t)ref[2], (uint32_t)ref[3], 0u, 0u);
+    }
+}
+
+hipError_t lbvh_gpu_collapse4(const PtBvhNode* d_nodes, uint32_t n_nodes, float4* d_wide, hipStream_t stream)
+{
+    if (n_nodes == 0) return hipSuccess;
+    if (!d_nodes || !d_wide) return hipErrorInvalidValue;
+    const uint32_t grid = (n_nodes + 255u) / 256u < 4096u ? (n_nodes + 255u) / 256u : 4096u;
+    hipLaunchKernelGGL(collapse4_kernel, dim3(grid), dim3(256), 0, stream, d_nodes, n_nodes, reinterpret_cast<uint4*>(d_wide));
+    return hipGetLastError();
+}
+
 }  // namespace pt

@@ -97,6 +97,8 @@ typedef struct PtStats {
     uint32_t beams_used;        /* 1: the primary pass took its candidates from the primary-beam lists of a resting view */
     uint64_t rays_first_pass_inline; /* pt_get_totals only: secondary rays the primary passes traced in registers (the first
                                         bounce of a 1-spp frame never enters a queue); part of `rays` */
+    uint64_t node_visits;       /* pt_get_totals only, scenes traversed in global memory: BVH node records read and ... */
+    uint64_t sphere_tests;      /* ... sphere records tested by the traversal kernels (the scene term of the byte accounting) */
 } PtStats;
 
 /* BVH node as traversed on the device (DESIGN.md "LBVH layout"); exposed for structural tests. */
