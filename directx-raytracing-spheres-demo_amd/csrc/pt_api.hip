@@ -40,7 +40,7 @@ struct EventPair {
 struct Knobs {
     int split = -1, traverse_blocks_per_cu = -1, fused_threads = -1, no_adaptive_grid = -1, shade_blocks_per_cu = -1, tail_threshold = -1,
         tail_blocks_per_cu = -1, loop_threads = -1, inline2_min_slots = -1, tail_after = -1, seg = -1, loop_use_tail = -1, fuse_loop = -1,
-        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1;
+        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1;
 };
 
 // Per-frame-in-flight state (see PtContext::lanes).
@@ -175,6 +175,44 @@ struct PtContext {
 };
 
 namespace {
+
+// roctx ranges (the reference brackets its passes with PIX events): with PT_ROCTX=1 every render call and BVH build /
+// refit is a named range on rocprofv3's marker timeline (rocprofv3 --marker-trace --kernel-trace).  libroctx64 is resolved at run
+// time, like RCCL; without the knob nothing is loaded or called.
+struct Roctx {
+    void* handle = nullptr;
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+
+Roctx& roctx()
+{
+    static Roctx r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    for (const char* name : { "librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1" }) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+    }
+    if (r.handle) {
+        r.push = reinterpret_cast<int (*)(const char*)>(dlsym(r.handle, "roctxRangePushA"));
+        r.pop = reinterpret_cast<int (*)()>(dlsym(r.handle, "roctxRangePop"));
+        if (!r.push || !r.pop) { r.push = nullptr; r.pop = nullptr; }
+    }
+    return r;
+}
+
+struct RoctxRange {
+    bool on = false;
+    RoctxRange(const PtContext* c, const char* name)
+    {
+        if (c && c->knobs.roctx > 0 && roctx().push) { (void)roctx().push(name); on = true; }
+    }
+    ~RoctxRange() { if (on) (void)roctx().pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
 
 // RCCL is resolved at run time, on first use: a single-GPU host never needs it, and inside a process that already carries an
 // RCCL (PyTorch's) the loader hands back that very copy (same SONAME), so one collective library serves the process.
@@ -403,7 +441,7 @@ Knobs read_knobs()
     k.inline2_min_slots = env_knob("PT_INLINE2_MIN_SLOTS"); k.tail_after = env_knob("PT_TAIL_AFTER"); k.seg = env_knob("PT_SEG");
     k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
     k.dyn_blocks_per_cu = env_knob("PT_DYN_BLOCKS_PER_CU"); k.debug_counts = std::getenv("PT_DEBUG_COUNTS") ? 1 : -1; k.sah = env_knob("PT_SAH");
-    k.sah_max_spheres = env_knob("PT_SAH_MAX_SPHERES"); k.beams = env_knob("PT_BEAMS"); k.wide = env_knob("PT_WIDE"); k.descent = env_knob("PT_DESCENT");
+    k.sah_max_spheres = env_knob("PT_SAH_MAX_SPHERES"); k.beams = env_knob("PT_BEAMS"); k.wide = env_knob("PT_WIDE"); k.descent = env_knob("PT_DESCENT"); k.roctx = env_knob("PT_ROCTX");
     return k;
 }
 
@@ -532,6 +570,7 @@ PtStatus beam_cache_lookup(PtContext* c, const PixelMap& pm, const uint32_t** li
 // size after every pass and switches to the looping kernel when it drops below PT_TAIL_THRESHOLD rays.
 PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, float4* out, PtStats* stats)
 {
+    const RoctxRange range(c, pm.mode == 0 ? "pt_render" : "pt_render_tiles");
     const uint32_t bounces = c->gs.Bounces, spp = c->gs.SamplesPerPixel;
     if (const uint32_t env = c->sd.EnvironmentLightTextureDescriptor; env != ~0u) {
         const size_t n_faces = c->sd.IsEnvironmentLightTextureCubeMap ? 6 : 1;
@@ -984,6 +1023,7 @@ PtStatus pt_build_accel(PtContext* c, PtAccelInfo* info)
 {
     if (!c) return PT_ERR_INVALID_ARG;
     if (!c->scene_set) return fail(c, PT_ERR_STATE, "pt_build_accel: no scene");
+    const RoctxRange range(c, "pt_build_accel");
     PT_HIP(c, hipSetDevice(c->device));
     const uint32_t n = c->n;
     PT_HIP(c, sync_all(c));
@@ -1109,6 +1149,7 @@ PtStatus pt_refit_accel(PtContext* c)
     if (!c) return PT_ERR_INVALID_ARG;
     Lane& L = c->lanes[c->next_lane];
     if (!c->accel_valid || !L.scene_private) return fail(c, PT_ERR_STATE, "pt_refit_accel: call pt_update_spheres first");
+    const RoctxRange range(c, "pt_refit_accel");
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, lbvh_gpu_refit(c->gpu_builder, L.d_sph, c->n, reinterpret_cast<PtBvhNode*>(L.d_nodes), L.d_sph_sorted, c->d_sorted_id,
                              L.d_refit_flags, L.d_refit_hdr, c->depth, L.stream));
@@ -1624,6 +1665,7 @@ PtStatus pt_gather(PtContext* c, const void* send_device, void* recv_device, uin
     if (!c) return PT_ERR_INVALID_ARG;
     if (!c->comm) return fail(c, PT_ERR_STATE, "pt_gather: no communicator (pt_comm_init)");
     if (root >= c->comm_world) return fail(c, PT_ERR_INVALID_ARG, "pt_gather: root >= world");
+    const RoctxRange range(c, "pt_gather");
     const bool is_root = c->comm_rank == root;
     if (bytes == 0) return PT_OK;
     if (is_root ? (!recv_device && c->comm_world > 1) : !send_device) return fail(c, PT_ERR_INVALID_ARG, "pt_gather: null buffer");
