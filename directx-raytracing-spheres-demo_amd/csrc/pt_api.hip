@@ -111,7 +111,8 @@ struct PtContext {
     uint32_t* d_tex_maps = nullptr;  // n * 8
     float4* d_rot = nullptr;         // n: the rotations as of pt_set_textures (single-lane contexts update it in stream order)
     std::vector<float4> h_rot;       // latest rotations (pt_update_rotations); lanes pick them up when they next render
-    uint64_t rot_gen = 0;
+    uint64_t rot_gen = 0;            // generation of h_rot (never reset) ...
+    uint64_t rot_master_gen = 0;     // ... and the generation d_rot holds: while they are equal every lane reads d_rot
     bool has_textures = false;
 
     // emissive spheres (row N4)
@@ -346,7 +347,7 @@ void free_textures(PtContext* c)
 // the lane that renders next uploads them into ITS copy on ITS stream (pinned staging, no wait for the other frames in flight).
 PtStatus sync_lane_rotations(PtContext* c, Lane& L)
 {
-    if (!c->has_textures || c->rot_gen == 0 || L.rot_gen == c->rot_gen) return PT_OK;
+    if (!c->has_textures || c->rot_gen == c->rot_master_gen || (L.rot_gen == c->rot_gen && L.rot_n == c->n)) return PT_OK;
     const uint32_t n = c->n;
     if (L.rot_n != n) {
         PT_HIP(c, hipStreamSynchronize(L.stream));
@@ -402,7 +403,7 @@ SceneView make_scene_view(const PtContext* c, const Lane* L = nullptr)
     sv.descent_cap = c->lds_scene ? 0u : knob_or(c->knobs.descent, 8u);
     sv.lds_scene = c->lds_scene ? 1u : 0u;
     for (int i = 0; i < 4; i++) sv.env[i] = c->sd.EnvironmentLightColor[i];
-    if (c->has_textures) { sv.tex = c->d_tex; sv.tex_maps = c->d_tex_maps; sv.rot = (L && L->d_rot && L->rot_gen == c->rot_gen) ? L->d_rot : c->d_rot; }
+    if (c->has_textures) { sv.tex = c->d_tex; sv.tex_maps = c->d_tex_maps; sv.rot = (c->rot_gen != c->rot_master_gen && L && L->d_rot && L->rot_gen == c->rot_gen) ? L->d_rot : c->d_rot; }
     sv.env_tex = c->sd.EnvironmentLightTextureDescriptor;  // ~0u == kNoTexture; render_common has checked it against the table
     sv.env_cube = c->sd.IsEnvironmentLightTextureCubeMap ? 1u : 0u;
     for (int r = 0; r < 3; r++)
@@ -1396,8 +1397,7 @@ PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_tex
     if (rotations)
         for (uint32_t i = 0; i < n; i++) c->h_rot[i] = make_float4(rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]);
     PT_HIP(c, hipMemcpy(c->d_rot, c->h_rot.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));  // (everything was synchronised above)
-    c->rot_gen = 0;  // generation 0 = the master copy; lanes hold private copies from the first pt_update_rotations on
-    for (auto& L : c->lanes) L.rot_gen = 0;
+    c->rot_master_gen = ++c->rot_gen;  // the master copy is current; lanes take private copies from the next pt_update_rotations on
     c->has_textures = true;
     return PT_OK;
 }

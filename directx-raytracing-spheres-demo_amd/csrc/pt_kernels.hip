@@ -636,8 +636,12 @@ __device__ __forceinline__ HitMaterial hit_material(const SceneView& sv, uint32_
             const uint32_t maps[kMapCount] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z };
             const float4 q = sv.rot[id];
             const f3 n_obj = quat_rotate(-q.x, -q.y, -q.z, q.w, r.hf.N);  // world -> object: the conjugate rotation
-            const f2 uv = sphere_uv(n_obj);
-            f3 T = quat_rotate(q.x, q.y, q.z, q.w, sphere_tangent(n_obj));
+            // ObjectToWorld = diag(1, 1, -1) * pose (Scene.ixx:197-199): the mesh-space normal is the z mirror of the object-space
+            // one (settled against the reference's screenshot with its own Earth map: without it the continents are mirrored)
+            const f3 n_mesh = make_f3(n_obj.x, n_obj.y, -n_obj.z);
+            const f2 uv = sphere_uv(n_mesh);
+            const f3 t_mesh = sphere_tangent(n_mesh);
+            f3 T = quat_rotate(q.x, q.y, q.z, q.w, make_f3(t_mesh.x, t_mesh.y, -t_mesh.z));
             if (!r.hf.front) T = -T;  // HitInfo::GetFrontTangent
             const MaterialEval me = evaluate_material(sv.tex, maps, uv, base, m1.x, emissive_color, metallic, roughness, transmission_m, Ns, T);
             base = me.BaseColor; emissive_color = me.EmissiveColor; metallic = me.Metallic; roughness = me.Roughness;

@@ -53,18 +53,33 @@ class HostLib:
             raise ValueError(f"pth_scene_at_time failed ({rc})")
         return spheres
 
-    def demo_textures(self, seed=0, time=0.0, textured=True, environment_map=False, return_scene_data=False):
+    def demo_textures(self, seed=0, time=0.0, textured=True, environment_map=False, return_scene_data=False, texture_dir=None):
         """TextureSet of the demo scene's textured objects (Alien-Metal, Moon, Earth: Source/MyScene.ixx:161-166, 285-295)
         at simulation time `time`, as the C++ host mirror builds it (MySceneDesc(seed, textured, environmentMap); procedural
         stand-ins for the reference's image files unless a loader is installed on the C++ side).  environment_map adds the
         lat-long environment light (MyScene.ixx:94-95) to the table; return_scene_data -> (TextureSet, PtSceneData), the
-        SceneData that names it."""
+        SceneData that names it.  texture_dir: a directory of decoded images (<stem>.ptex, host/Texture.hpp LoadRawTexture -- e.g.
+        tests/golden/textures, the reference's own assets) to use instead of the stand-ins."""
+        flags = (1 if textured else 0) | (2 if environment_map else 0)
+        saved = os.environ.get("PT_TEXTURE_DIR")
+        if texture_dir is not None:
+            os.environ["PT_TEXTURE_DIR"] = str(texture_dir)  # read by DefaultTextureLoader inside the calls below
+        elif saved is not None:
+            del os.environ["PT_TEXTURE_DIR"]
+        try:
+            return self._demo_textures(seed, time, flags, return_scene_data)
+        finally:
+            if saved is not None:
+                os.environ["PT_TEXTURE_DIR"] = saved
+            else:
+                os.environ.pop("PT_TEXTURE_DIR", None)
+
+    def _demo_textures(self, seed, time, flags, return_scene_data):
         from .abi_types import TEXTURE_MAP_COUNT, TEXTURE_RGBA8_UNORM_SRGB, TEXTURE_RGBA32_FLOAT, PtObjectTextures, PtSceneData
         from .textures import TextureSet
         fn = self.lib.pth_demo_textures_ex
         fn.restype = C.c_int
         fn.argtypes = [C.c_uint32, C.c_double, C.c_uint32] + [C.c_void_p] * 8
-        flags = (1 if textured else 0) | (2 if environment_map else 0)
         nt, no, nb = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
         sd = PtSceneData()
         fn(seed, time, flags, C.byref(nt), C.byref(no), C.byref(nb), None, None, None, None, None)

@@ -9,6 +9,9 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <string>
 #include <vector>
@@ -154,9 +157,45 @@ inline Texture Sky(uint32_t w, uint32_t h, unsigned seed)
 
 }  // namespace procedural
 
-// Default loader: stand-ins keyed by the reference's file names (any other name gets a neutral grey / flat normal map).
+// Decoded image files (replaces the DirectXTex loaders of Source/TextureHelpers.ixx:34-138: WIC / DDS / HDR / EXR / TGA decoding is
+// out of scope here -- this path takes images already decoded to 8-bit RGBA in a minimal container).  ".ptex": the ASCII tag "PTEX",
+// then width and height as little-endian uint32, then width * height * 4 bytes, rows top to bottom.  tests/golden/make_textures.py
+// writes the reference's own Assets/Textures in this form (decoded and reduced with PIL in the build container).
+inline bool LoadRawTexture(const std::string& file, Texture& out)
+{
+    FILE* f = std::fopen(file.c_str(), "rb");
+    if (!f) return false;
+    char tag[4];
+    uint32_t wh[2];
+    bool ok = std::fread(tag, 1, 4, f) == 4 && std::memcmp(tag, "PTEX", 4) == 0 && std::fread(wh, 4, 2, f) == 2 && wh[0] > 0 && wh[1] > 0 && wh[0] <= 16384 && wh[1] <= 16384;
+    if (ok) {
+        out.Width = wh[0]; out.Height = wh[1];
+        out.Pixels.resize(size_t(wh[0]) * wh[1] * 4);
+        ok = std::fread(out.Pixels.data(), 1, out.Pixels.size(), f) == out.Pixels.size();
+    }
+    std::fclose(f);
+    return ok;
+}
+
+inline std::string TextureStem(const std::string& path)
+{
+    const size_t slash = path.find_last_of("/\\"), start = slash == std::string::npos ? 0 : slash + 1, dot = path.find_last_of('.');
+    return path.substr(start, dot == std::string::npos || dot < start ? std::string::npos : dot - start);
+}
+
+// Default loader: with PT_TEXTURE_DIR set, "<dir>/<file stem>.ptex" (e.g. Earth_BaseColor.ptex for .../Earth_BaseColor.jpg), colour maps
+// marked sRGB as Scene.ixx:157 does; otherwise -- and for files that directory lacks, like the reference's own missing
+// Alien-Metal_Normal.png and its EXR environment -- procedural stand-ins keyed by the reference's file names (any other name gets a
+// neutral grey / flat normal map).
 inline Texture DefaultTextureLoader(const std::string& path, uint32_t type)
 {
+    if (const char* dir = std::getenv("PT_TEXTURE_DIR"); dir && *dir) {
+        Texture t;
+        if (LoadRawTexture(std::string(dir) + "/" + TextureStem(path) + ".ptex", t)) {
+            t.ForceSRGB = type == TextureMapType::BaseColor || type == TextureMapType::EmissiveColor;
+            return t;
+        }
+    }
     const auto has = [&](const char* s) { return path.find(s) != std::string::npos; };
     constexpr float sea[3] = { 0.05f, 0.15f, 0.45f }, land[3] = { 0.25f, 0.45f, 0.15f };
     constexpr float mare[3] = { 0.25f, 0.25f, 0.27f }, highland[3] = { 0.65f, 0.63f, 0.6f };

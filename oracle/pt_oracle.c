@@ -1013,9 +1013,13 @@ static material_eval evaluate_material(const tex_ctx *tc, const PtMaterial *m, c
     float q[4] = { 0, 0, 0, 1 };
     if (tc->t->rotations) memcpy(q, tc->t->rotations + 4u * (size_t)h->id, sizeof q);
     v3 n_obj = quat_rotate(-q[0], -q[1], -q[2], q[3], h->N); /* world -> object */
-    float nn[3] = { n_obj.x, n_obj.y, n_obj.z }, uv[2], s[4];
+    /* ObjectToWorld = diag(1, 1, -1) * pose (Scene.ixx:197-199): the mesh-space normal is the z mirror of the object-space one (the
+     * rotations handed over are the poses conjugated with that mirror).  Settled against Screenshots/Raytracing-Spheres.png with the
+     * reference's own Earth map: without the mirror the continents come out mirrored. */
+    float nn[3] = { n_obj.x, n_obj.y, -n_obj.z }, uv[2], s[4];
     oracle_sphere_uv(nn, uv);
-    v3 T = quat_rotate(q[0], q[1], q[2], q[3], sphere_tangent(n_obj));
+    v3 t_mesh = sphere_tangent(V3(nn[0], nn[1], nn[2]));
+    v3 T = quat_rotate(q[0], q[1], q[2], q[3], V3(t_mesh.x, t_mesh.y, -t_mesh.z));
     if (!h->front) T = v_neg(T); /* GetFrontTangent */
 
     if ((e.base.x > 0.0f || e.base.y > 0.0f || e.base.z > 0.0f) && maps[PT_TEXTURE_MAP_BASE_COLOR].Descriptor != ~0u) {

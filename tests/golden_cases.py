@@ -32,6 +32,15 @@ def cases(dxrs, host):
     ts, sd3 = host.demo_textures(0, 3.0, environment_map=True, return_scene_data=True)
     out.append(dict(file="n1_textured_envmap_crop_592_130_96x64.npy", spheres=s3, materials=m2, sd=sd3, cam=host.camera(1280, 720, jitter_index=3),
                     gs=t.graphics_settings(1280, 720, frame_index=3, bounces=6, spp=2), rect=(592, 130, 96, 64), textures=ts))
+    # row N1 with the reference's OWN images (tests/golden/textures: Assets/Textures decoded and reduced by tests/golden/make_textures.py):
+    # Earth + Moon crop, and the Alien-Metal hero (albedo + metallic + roughness maps), sky-lit, after 3 s of motion
+    import os
+    tex_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "textures")
+    tr = host.demo_textures(0, 3.0, texture_dir=tex_dir)
+    out.append(dict(file="n1_real_textures_earth_moon_crop_400_100_320x96.npy", spheres=s3, materials=m2, sd=sd2, cam=host.camera(1280, 720, jitter_index=2),
+                    gs=t.graphics_settings(1280, 720, frame_index=2, bounces=4, spp=2), rect=(400, 100, 320, 96), textures=tr))
+    out.append(dict(file="n1_real_textures_alien_metal_crop_500_330_96x64.npy", spheres=s3, materials=m2, sd=sd2, cam=host.camera(1280, 720, jitter_index=2),
+                    gs=t.graphics_settings(1280, 720, frame_index=2, bounces=4, spp=2), rect=(500, 330, 96, 64), textures=tr))
     # row N4: sphere-light direct illumination on the demo scene (its emissive spheres), 1 spp
     out.append(dict(file="n4_di_crop_560_360_96x48.npy", spheres=s2, materials=m2, sd=sd2, cam=host.camera(1280, 720, jitter_index=1),
                     gs=t.graphics_settings(1280, 720, frame_index=1, bounces=4, spp=1, di=True), rect=(560, 360, 96, 48), textures=None))

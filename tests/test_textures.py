@@ -269,3 +269,32 @@ def test_gpu_texture_api_errors_and_rotation_update(dxrs, host, oracle, renderer
     with pytest.raises(RuntimeError):
         renderer.update_rotations(ts.rotations[:3])
     renderer.set_textures(None)
+
+
+def test_reference_texture_fixtures_load_through_the_host_mirror(dxrs, host):
+    """tests/golden/textures/*.ptex = the reference's Assets/Textures decoded in the build container (tests/golden/make_textures.py).
+    host/Texture.hpp's loader (PT_TEXTURE_DIR) puts them into the demo scene's table where Source/MyScene.ixx:161-166, 285-295 names
+    them, colour maps flagged sRGB as Scene.ixx:157 does; the file the reference names but does not ship (Alien-Metal_Normal.png)
+    keeps its stand-in."""
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "textures")
+    names = sorted(os.listdir(d))
+    assert names == ["Alien-Metal_Albedo.ptex", "Alien-Metal_Metallic.ptex", "Alien-Metal_Roughness.ptex", "Earth_BaseColor.ptex", "Earth_Normal.ptex",
+                     "Moon_BaseColor.ptex", "Moon_Normal.ptex"]
+    real = host.demo_textures(0, 0.0, texture_dir=d)
+    stand_in = host.demo_textures(0, 0.0)
+    t = dxrs.types
+    assert len(real.images) == len(stand_in.images) == 8 and np.array_equal(real.maps, stand_in.maps)
+    raw = {n[:-5]: np.fromfile(os.path.join(d, n), dtype=np.uint8) for n in names}
+    # object 0 = Alien-Metal, then Moon and Earth near the end of the object list (MySceneDesc order)
+    alien = 0
+    for k, stem in ((t.TEXTURE_MAP_BASE_COLOR, "Alien-Metal_Albedo"), (t.TEXTURE_MAP_METALLIC, "Alien-Metal_Metallic"), (t.TEXTURE_MAP_ROUGHNESS, "Alien-Metal_Roughness")):
+        img, fmt = real.images[int(real.maps[alien, k])]
+        assert img.shape == (256, 256, 4) and np.array_equal(img.reshape(-1), raw[stem][12:])
+        assert (fmt == t.TEXTURE_RGBA8_UNORM_SRGB) == (k == t.TEXTURE_MAP_BASE_COLOR)
+    normal_img, _ = real.images[int(real.maps[alien, t.TEXTURE_MAP_NORMAL])]
+    assert np.array_equal(normal_img, stand_in.images[int(stand_in.maps[alien, t.TEXTURE_MAP_NORMAL])][0])  # not shipped by the reference
+    earth = [i for i in range(real.n) if real.maps[i, t.TEXTURE_MAP_BASE_COLOR] != 0xFFFFFFFF and real.images[int(real.maps[i, t.TEXTURE_MAP_BASE_COLOR])][0].shape == (256, 512, 4)]
+    assert len(earth) == 2  # Moon, Earth
+    blue = [real.images[int(real.maps[i, t.TEXTURE_MAP_BASE_COLOR])][0][..., :3].mean((0, 1)) for i in earth]
+    assert any(b[2] > b[0] + 40 for b in blue)  # the Earth is blue, the Moon is grey

@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--time", type=float, default=0.0, help="simulation time of the closed-form motion")
     ap.add_argument("--textures", action="store_true", help="textured Alien-Metal / Moon / Earth (procedural stand-ins)")
     ap.add_argument("--env-map", action="store_true", help="lat-long HDR environment light (MyScene.ixx:94-95; procedural stand-in) instead of the sky")
-    ap.add_argument("--texture-dir", default=None, help="directory with the reference's Assets/Textures files: use the real images")
+    ap.add_argument("--texture-dir", default=None, help="directory of decoded images (<stem>.ptex, e.g. tests/golden/textures = the reference's Assets/Textures): use them instead of the stand-ins")
     ap.add_argument("--operator", choices=["saturate", "reinhard", "aces"], default="aces")
     ap.add_argument("--exposure", type=float, default=0.0, help="stops")
     args = ap.parse_args()
@@ -44,17 +44,12 @@ def main():
     r = dxrs_amd.Renderer(stream=stream.cuda_stream)
     textured = bool(args.textures or args.texture_dir)
     if textured or args.env_map:
-        ts, sd_env = host.demo_textures(0, args.time, textured=textured, environment_map=args.env_map, return_scene_data=True)
+        # --texture-dir: decoded images (<stem>.ptex; tests/golden/textures holds the reference's own assets) through the host mirror's loader
+        ts, sd_env = host.demo_textures(0, args.time, textured=textured, environment_map=args.env_map, return_scene_data=True, texture_dir=args.texture_dir)
         if args.env_map:
             sd = sd_env
     r.set_scene(spheres, materials, sd)
     if textured or args.env_map:
-        if args.texture_dir and textured:  # replace the stand-ins by decoded files, same slots (order: MyScene.ixx:161-166, 285-295)
-            from dxrs_amd.textures import load_image
-            names = ["Alien-Metal_Albedo.png", "Alien-Metal_Metallic.png", "Alien-Metal_Roughness.png", "Alien-Metal_Normal.png",
-                     "Moon_BaseColor.jpg", "Moon_Normal.jpg", "Earth_BaseColor.jpg", "Earth_Normal.jpg"]
-            for i, name in enumerate(names):
-                ts.images[i] = (np.ascontiguousarray(load_image(os.path.join(args.texture_dir, name))), ts.images[i][1])
         r.set_textures(ts)
     w, h, n = args.width, args.height, args.width * args.height
     gs = t.graphics_settings(w, h, bounces=args.bounces, spp=args.spp)
