@@ -259,3 +259,48 @@ def test_primary_beam_cache_follows_the_view(dxrs, host, oracle, renderer):
     small = host.scene(dxrs.host.SCENE_SMALL, seed=0)
     renderer.set_scene(*small)
     check(cam_b2, "b2", False, scene=small); check(cam_b2, "b2", False, scene=small); check(cam_b2, "b2", True, scene=small)
+
+
+def test_rect_bounds_do_not_wrap(dxrs, host, renderer):
+    """x + w computed in 32 bits used to wrap (x = 0xFFFFFFFF, w = 2 passed the check)"""
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_SMALL, seed=0)
+    renderer.set_scene(spheres, materials, sd); renderer.set_camera(host.camera(64, 48)); renderer.set_constants(dxrs.types.graphics_settings(64, 48, bounces=1))
+    for rect in ((0xFFFFFFFF, 0, 2, 1), (0, 0xFFFFFFFF, 1, 2), (63, 0, 2, 1), (0, 47, 1, 2), (64, 0, 1, 1), (0, 0, 0, 1)):
+        with pytest.raises(dxrs.PtError):
+            renderer.render(rect)
+    img, _ = renderer.render((63, 47, 1, 1))
+    assert img.shape == (1, 1, 4)
+
+
+def test_same_output_buffer_on_consecutive_frames_in_flight(dxrs, host):
+    """with N frames in flight the caller is meant to rotate over N output buffers; handing the SAME buffer to
+    consecutive calls used to let two lanes write it at once.  The context now orders such frames itself: every frame read back
+    after its call must be that frame, bit for bit."""
+    import torch
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    w, h = 640, 360
+    ts = torch.cuda.Stream()  # the caller's stream: the context orders its frames against it, the read-backs below run on it
+    ref = dxrs.Renderer(frames_in_flight=1)
+    r = dxrs.Renderer(stream=ts.cuda_stream, frames_in_flight=3)
+    try:
+        gs = dxrs.types.graphics_settings(w, h, bounces=6, spp=1)
+        for x in (ref, r):
+            x.set_scene(spheres, materials, sd)
+        buf = torch.empty((h * w, 4), dtype=torch.float32, device="cuda")
+        snap = [torch.empty_like(buf) for _ in range(7)]
+        want = []
+        for k in range(7):
+            gs.FrameIndex = k
+            cam = host.camera(w, h, jitter_index=k)
+            ref.set_camera(cam); ref.set_constants(gs)
+            want.append(ref.render()[0].reshape(h * w, 4))
+            r.set_camera(cam); r.set_constants(gs)
+            r.render_device(buf.data_ptr())       # the same buffer every time, no synchronisation in between
+            with torch.cuda.stream(ts):
+                snap[k].copy_(buf, non_blocking=True)  # the consumer, on the caller's stream
+        r.synchronize()
+        torch.cuda.synchronize()
+        for k in range(7):
+            assert np.array_equal(snap[k].cpu().numpy().view(np.uint32), want[k].view(np.uint32)), f"frame {k}"
+    finally:
+        r.close(); ref.close()
