@@ -43,7 +43,7 @@ def main():
                      "FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md)", "kernels": {}}
     for k, c in agg.items():
         per = lambda name: c[name] / cnt[k][name] if cnt[k][name] else None
-        e = {"launches": int(max(cnt[k].values()))}
+        e = {"launches": int(min(cnt[k].values()))}  # (every counter but SQ_WAVES is collected in exactly one pass)
         if per("FETCH_SIZE") is not None and per("WRITE_SIZE") is not None:
             e.update(fetch_kb_per_launch_raw=per("FETCH_SIZE"), write_kb_per_launch=per("WRITE_SIZE"), hbm_bytes_per_launch=(2.0 * per("FETCH_SIZE") + per("WRITE_SIZE")) * 1024.0)
         if per("SQ_WAVES"):
