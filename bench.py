@@ -412,9 +412,19 @@ def roofline_object(args, w, h, world, tiled, prof, tot_ev, qs, elapsed, elapsed
 def init_cabi_gather(r, dist, torch, dev, rank, world):
     """pt_comm_init on every rank (id from rank 0 through the torch process group) + a self-check gather of a known pattern.
     Returns True when every rank saw it work; any failure is symmetric (all ranks fall back together)."""
+    # every rank first shows it can load RCCL at all (a rank that cannot must not leave the others waiting in ncclCommInitRank)
+    try:
+        my_id, can = r.comm_unique_id(), 1
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] rank {rank}: RCCL cannot be loaded through the C-ABI ({e}); using torch.distributed.gather", file=sys.stderr)
+        my_id, can = None, 0
+    flag = torch.tensor([can], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        return False
     ok = 1
     try:
-        ids = [r.comm_unique_id() if rank == 0 else None]
+        ids = [my_id if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         r.comm_init(ids[0], rank, world)
         n = 4096
