@@ -678,18 +678,26 @@ __device__ __forceinline__ f3 di_estimate(const SceneView& sv, const FrameParams
     const LightSample s = sample_sphere_cone(hm.hf.P, load3(ls), ls.w, u1, u2);
     const Surf surf = surf_init(hm.hf.front, hm.hf.N, hm.Ns);
     if (light != id && s.valid && dot(surf.FrontNg, s.L) > 0.0f) {
-        float t2;
-        uint32_t id2;
-        const f3 so = spawn_origin(hm.hf.P, hm.hf.N, hm.hf.offset, s.L);
-        trace(so, s.L, t2, id2);
-        rays++;
-        if (id2 == light) {
-            const f3 V = -d;
-            float w[3];
-            lobe_weights(hm.bsdf, surf, V, w);
-            const f3 f = bsdf_eval_reflective(hm.bsdf, surf, s.L, V, w);
-            const f3 le = hit_material<kTex>(sv, light, so, s.L, t2, false).emission;
-            est = (le * f) * (s.inv_pdf * (float)sv.n_lights);
+        const f3 V = -d;
+        float w[3];
+        lobe_weights(hm.bsdf, surf, V, w);
+        const f3 f = bsdf_eval_reflective(hm.bsdf, surf, s.L, V, w);
+        // No shadow ray for a contribution that cannot matter: the estimate's upper bound with the emitter's untextured radiance
+        // (maps modulate it downwards) is below kDiNegligible -- a mirror-like primary surface seen off its specular direction,
+        // i.e. most of the demo's ground.  (Bias below 1e-7 of unit radiance per pixel; spec of this row, not of the reference.)
+        const float4 lm = sv.mats[light * 4 + 1];  // {EmissiveStrength, EmissiveColor}
+        const float k = s.inv_pdf * (float)sv.n_lights;
+        const float bound = pt_max(f.x * lm.y, pt_max(f.y * lm.z, f.z * lm.w)) * (lm.x * k);
+        if (bound > kDiNegligible) {
+            float t2;
+            uint32_t id2;
+            const f3 so = spawn_origin(hm.hf.P, hm.hf.N, hm.hf.offset, s.L);
+            trace(so, s.L, t2, id2);
+            rays++;
+            if (id2 == light) {
+                const f3 le = hit_material<kTex>(sv, light, so, s.L, t2, false).emission;
+                est = (le * f) * k;
+            }
         }
     }
     if (!(est.x > 0.0f || est.y > 0.0f || est.z > 0.0f) || !is_finite(est.x) || !is_finite(est.y) || !is_finite(est.z))

@@ -54,6 +54,7 @@ PT_HD f3 bsdf_eval_reflective(const Bsdf& b, const Surf& s, f3 L, f3 V, const fl
     return bsdf_eval(b, s, L, V, w, kLobeDiffuse) + bsdf_eval(b, s, L, V, w, kLobeSpecular);
 }
 
+constexpr float kDiNegligible = 1e-7f;  // upper bound of an estimate below which no shadow ray is cast (di_estimate)
 constexpr uint32_t kDiRngSalt = 0x44495F31u;  // the DI pass has its own per-pixel stream: rng_init(px, py, FrameIndex ^ salt)
 
 }  // namespace pt

@@ -1064,6 +1064,7 @@ static material_eval evaluate_material(const tex_ctx *tc, const PtMaterial *m, c
  * hit of a pixel with valid DI contributes no emission) and :381 (radiance += DI).  One emitter chosen uniformly
  * (LightPreparation.ixx:52-70 enumerates them), one direction uniform in the cone it subtends, own RNG stream.
  * ---------------------------------------------------------------------------------------------------------------- */
+#define DI_NEGLIGIBLE 1e-7f
 #define DI_RNG_SALT 0x44495F31u
 
 typedef struct { const uint32_t *ids; uint32_t n; } light_list;
@@ -1138,19 +1139,26 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
         surf_t sv;
         surf_init(&sv, primary.front, primary.N, primary.shadingN);
         if (light != primary.id && ok && v_dot(sv.FrontNg, L) > 0.0f) {
+            v3 V = v_neg(d);
+            float w[3];
+            lobe_weights(&primary_bsdf, &sv, V, w);
+            v3 f = v_add(bsdf_eval(&primary_bsdf, &sv, L, V, w, 0), bsdf_eval(&primary_bsdf, &sv, L, V, w, 1));
+            /* no shadow ray for a contribution that cannot matter (upper bound with the emitter's untextured radiance <= 1e-7) */
+            const PtMaterial *lmc = &mat[light];
+            const float kk = inv_pdf * (float)lights->n;
+            const float bound = f_max(f.x * lmc->EmissiveColor[0], f_max(f.y * lmc->EmissiveColor[1], f.z * lmc->EmissiveColor[2])) * (lmc->EmissiveStrength * kk);
             hit_t sh;
-            cast_ray(accel, sph, n, spawn_origin(primary.P, primary.N, primary.offset, L), L, 0.0f, INFINITY, &sh);
-            rays++;
+            sh.hit = 0;
+            if (bound > DI_NEGLIGIBLE) {
+                cast_ray(accel, sph, n, spawn_origin(primary.P, primary.N, primary.offset, L), L, 0.0f, INFINITY, &sh);
+                rays++;
+            }
             if (sh.hit && sh.id == light) {
-                v3 V = v_neg(d);
-                float w[3];
-                lobe_weights(&primary_bsdf, &sv, V, w);
-                v3 f = v_add(bsdf_eval(&primary_bsdf, &sv, L, V, w, 0), bsdf_eval(&primary_bsdf, &sv, L, V, w, 1));
                 /* the emitter's radiance at the point the shadow ray reaches: Material::GetEmission after EvaluateMaterial (an
                  * emissive map modulates the constant; LightPreparation.hlsl:84-88 likewise reads the map for its triangles) */
                 const material_eval lme = evaluate_material(tc, &mat[light], &sh);
                 v3 le = v_scale(lme.emissive_color, lme.emissive_strength);
-                DI = v_scale(v_mul(le, f), inv_pdf * (float)lights->n);
+                DI = v_scale(v_mul(le, f), kk);
             }
         }
         /* NaN / inf / negative estimates count as no light.  The reference gates :302 on any(DI > 0); with this one-sample
