@@ -29,7 +29,8 @@ class PtError(RuntimeError):
 
 
 def hip_library_path():
-    return os.path.join(_PKG, "libpt_hip.so")
+    # PT_HIP_LIB: another build of the same library (A/B runs of kernel variants on one box: tools/experiments)
+    return os.environ.get("PT_HIP_LIB") or os.path.join(_PKG, "libpt_hip.so")
 
 
 class HipLib:

@@ -198,33 +198,38 @@ PT_HD MaterialEval evaluate_material(const TexView* tex, const uint32_t* maps, f
     MaterialEval m;
     m.BaseColor = base; m.EmissiveColor = emissive_color; m.EmissiveStrength = emissive_strength;
     m.Metallic = metallic; m.Roughness = roughness; m.Transmission = transmission; m.Ns = Ns_in;
-    float s[4];
-    if ((base.x > 0.0f || base.y > 0.0f || base.z > 0.0f) && maps[kMapBaseColor] != kNoTexture) {  // :61-72 (the reference also tests alpha > 0; with rgb == 0 the product is 0 either way)
-        sample_bilinear(tex[maps[kMapBaseColor]], uv, s);
-        m.BaseColor = make_f3(base.x * s[0], base.y * s[1], base.z * s[2]);
-    }
+    // One pass over the map types in TextureMapType order, ONE instance of the sampler (the seven inlined copies of the first
+    // version cost registers and instruction cache); the conditions and the order of application are the reference's.
     const f3 emission = emissive_color * emissive_strength;
-    if ((emission.x > 0.0f || emission.y > 0.0f || emission.z > 0.0f) && maps[kMapEmissiveColor] != kNoTexture) {  // :178-184
-        sample_bilinear(tex[maps[kMapEmissiveColor]], uv, s);
-        m.EmissiveColor = make_f3(emissive_color.x * s[0], emissive_color.y * s[1], emissive_color.z * s[2]);
-    }
-    if (maps[kMapMetallicRoughness] != kNoTexture) {  // :186-196
-        if (metallic > 0.0f || roughness > 0.0f) {
-            sample_bilinear(tex[maps[kMapMetallicRoughness]], uv, s);
-            m.Metallic = metallic * s[2];
-            m.Roughness = roughness * s[1];
+    const bool has_mr = maps[kMapMetallicRoughness] != kNoTexture;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (uint32_t k = 0; k < kMapCount; k++) {
+        const uint32_t t = maps[k];
+        if (t == kNoTexture) continue;
+        bool need;
+        switch (k) {
+            case kMapBaseColor: need = base.x > 0.0f || base.y > 0.0f || base.z > 0.0f; break;  // :61-72 (the reference also tests alpha > 0; with rgb == 0 the product is 0 either way)
+            case kMapEmissiveColor: need = emission.x > 0.0f || emission.y > 0.0f || emission.z > 0.0f; break;  // :178-184
+            case kMapMetallic: need = !has_mr && metallic > 0.0f; break;                                  // :197-213
+            case kMapRoughness: need = !has_mr && roughness > 0.0f; break;
+            case kMapMetallicRoughness: need = metallic > 0.0f || roughness > 0.0f; break;                  // :186-196
+            case kMapTransmission: need = m.Metallic < 1.0f && transmission > 0.0f; break;                  // :215-221, :74-85
+            default: need = T.x != 0.0f || T.y != 0.0f || T.z != 0.0f; break;                               // kMapNormal, :222-230
         }
-    } else {  // :197-213
-        if (metallic > 0.0f && maps[kMapMetallic] != kNoTexture) { sample_bilinear(tex[maps[kMapMetallic]], uv, s); m.Metallic = metallic * s[0]; }
-        if (roughness > 0.0f && maps[kMapRoughness] != kNoTexture) { sample_bilinear(tex[maps[kMapRoughness]], uv, s); m.Roughness = roughness * s[0]; }
-    }
-    if (m.Metallic < 1.0f && transmission > 0.0f && maps[kMapTransmission] != kNoTexture) {  // :215-221, :74-85
-        sample_bilinear(tex[maps[kMapTransmission]], uv, s);
-        m.Transmission = transmission * s[0];
-    }
-    if ((T.x != 0.0f || T.y != 0.0f || T.z != 0.0f) && maps[kMapNormal] != kNoTexture) {  // :222-230
-        sample_bilinear(tex[maps[kMapNormal]], uv, s);
-        m.Ns = perturb_normal(Ns_in, T, s[0], s[1]);
+        if (!need) continue;
+        float s[4];
+        sample_bilinear(tex[t], uv, s);
+        switch (k) {
+            case kMapBaseColor: m.BaseColor = make_f3(base.x * s[0], base.y * s[1], base.z * s[2]); break;
+            case kMapEmissiveColor: m.EmissiveColor = make_f3(emissive_color.x * s[0], emissive_color.y * s[1], emissive_color.z * s[2]); break;
+            case kMapMetallic: m.Metallic = metallic * s[0]; break;
+            case kMapRoughness: m.Roughness = roughness * s[0]; break;
+            case kMapMetallicRoughness: m.Metallic = metallic * s[2]; m.Roughness = roughness * s[1]; break;
+            case kMapTransmission: m.Transmission = transmission * s[0]; break;
+            default: m.Ns = perturb_normal(Ns_in, T, s[0], s[1]); break;
+        }
     }
     return m;
 }
