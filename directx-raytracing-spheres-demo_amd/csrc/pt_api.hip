@@ -621,14 +621,15 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     c->next_lane = (c->next_lane + 1) % c->n_lanes;
     // Primary beams: use the cached candidate lists when this frame's view is the one they were built for; start a build
     // (side stream) when the view has rested for two consecutive frames.  PT_BEAMS=0 switches them off, for A/B runs.
+    // (Building lists in front of EVERY frame of a moving view was measured, with the tree staged in LDS for the build: the
+    // animated C2 frame went from 0.099 to 0.117 ms -- the build lengthens the frame's dependent chain by more than the primary
+    // pass gains.  Resting views only.)
     const uint32_t* beam_lists = nullptr;
     if (!split && !L.scene_private && c->n_nodes > 0 && knob_or(c->knobs.beams, 1u) != 0 && std::fabs(c->cam.Jitter[0]) <= 0.5f && std::fabs(c->cam.Jitter[1]) <= 0.5f) {
         if ((st = beam_cache_lookup(c, pm, &beam_lists)) != PT_OK) return st;
-        if (beam_lists) {
-            if (hipEventQuery(c->beam.ev_ready) != hipSuccess) {
-                (void)hipGetLastError();
-                PT_HIP(c, hipStreamWaitEvent(L.stream, c->beam.ev_ready, 0));
-            }
+        if (beam_lists && hipEventQuery(c->beam.ev_ready) != hipSuccess) {
+            (void)hipGetLastError();
+            PT_HIP(c, hipStreamWaitEvent(L.stream, c->beam.ev_ready, 0));
         }
     } else {
         c->beam.last_key.clear();

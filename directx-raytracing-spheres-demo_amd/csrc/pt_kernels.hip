@@ -348,14 +348,26 @@ __device__ __forceinline__ bool beam_meets_leaf(const Beam& b, f3 lo, f3 hi)
     return meets;
 }
 
-template <typename StackT>
+// kLds: the workgroup stages the tree into LDS first (LDS-resident scenes): a lane's walk is a chain of ~50-100 dependent node reads, and
+// from LDS it takes ~10 us for a 1080p frame where L2 latency made it 58 -- fast enough to run in front of EVERY frame of a moving view.
+template <bool kLds, typename StackT>
 __global__ __launch_bounds__(256) void beam_kernel(SceneView sv, PixelMap pm, FrameParams fp, uint32_t* __restrict__ lists)
 {
     extern __shared__ float4 smem[];
-    StackT* stack = reinterpret_cast<StackT*>(smem) + threadIdx.x;
     const uint32_t stride = blockDim.x;
     const uint32_t n_blocks = pm.n_slots >> 6;
-    const float4* __restrict__ nodes = sv.nodes;
+    const float4* nodes = sv.nodes;
+    const uint32_t* ids = sv.sorted_id;
+    StackT* stack;
+    if (kLds) {
+        stage_scene(sv, smem);
+        nodes = smem;
+        ids = reinterpret_cast<const uint32_t*>(smem + sv.n_nodes * 4u + sv.n);
+        stack = reinterpret_cast<StackT*>(reinterpret_cast<char*>(smem) + scene_lds_bytes(sv.n_nodes, sv.n));
+    } else {
+        stack = reinterpret_cast<StackT*>(smem);
+    }
+    stack += threadIdx.x;
     for (uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x; tile < n_blocks; tile += gridDim.x * blockDim.x) {
         uint32_t* rec = lists + (size_t)tile * kBeamRecord;
         const PixelRef pr = slot_to_pixel(pm, tile << 6);  // the block's first pixel
@@ -363,7 +375,7 @@ __global__ __launch_bounds__(256) void beam_kernel(SceneView sv, PixelMap pm, Fr
         if (pr.valid) {
             const Beam b = make_beam(fp.cam, pr.px, pr.py);
             if (sv.n == 1) {
-                rec[1] = sv.sorted_id[0];
+                rec[1] = ids[0];
                 count = 1;
             } else {
                 int node = 0;
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(256) void beam_kernel(SceneView sv, PixelMap pm, Fr
                         if (h0) { node = c0; continue; }
                         if (h1) { node = c1; continue; }
                     } else {
-                        if (count < kBeamListCap) rec[1 + count] = sv.sorted_id[~(uint32_t)node];
+                        if (count < kBeamListCap) rec[1 + count] = ids[~(uint32_t)node];
                         if (++count > kBeamListCap) break;  // overflow: the wave will traverse per ray
                     }
                     if (sp == 0) break;
@@ -1442,10 +1454,17 @@ hipError_t launch_beams(const SceneView& sv, const PixelMap& pm, const FramePara
     const uint32_t n_blocks = pm.n_slots >> 6;
     if (n_blocks == 0) return hipSuccess;
     const bool small = sv.n_nodes < 32767u;
-    const uint32_t lds = 256u * (sv.stack_depth + 1u) * (small ? 2u : 4u);
+    const uint32_t stack_bytes = 256u * (sv.stack_depth + 1u) * (small ? 2u : 4u);
+    const uint32_t lds = (sv.lds_scene ? scene_lds_bytes(sv.n_nodes, sv.n) : 0u) + stack_bytes;
     const uint32_t grid = (n_blocks + 255u) / 256u;
-    if (small) hipLaunchKernelGGL((beam_kernel<uint16_t>), dim3(grid), dim3(256), lds, stream, sv, pm, fp, lists);
-    else hipLaunchKernelGGL((beam_kernel<uint32_t>), dim3(grid), dim3(256), lds, stream, sv, pm, fp, lists);
+#define PT_BEAM(L, T)                                                                                                                            \
+    do {                                                                                                                                          \
+        if (lds + kStaticLdsMargin > 65536u) (void)hipFuncSetAttribute((const void*)beam_kernel<L, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((beam_kernel<L, T>), dim3(grid), dim3(256), lds, stream, sv, pm, fp, lists);                                           \
+    } while (0)
+    if (sv.lds_scene) { if (small) PT_BEAM(true, uint16_t); else PT_BEAM(true, uint32_t); }
+    else { if (small) PT_BEAM(false, uint16_t); else PT_BEAM(false, uint32_t); }
+#undef PT_BEAM
     return hipGetLastError();
 }
 

@@ -60,3 +60,19 @@ def renderer(dxrs):
     r = dxrs.Renderer(device=0)
     yield r
     r.close()
+
+
+@pytest.fixture(scope="session")
+def renderer_no_beams(dxrs):
+    """A context created with PT_BEAMS=0 (the knobs are read once, at pt_create): every primary ray traverses the BVH."""
+    old = os.environ.get("PT_BEAMS")
+    os.environ["PT_BEAMS"] = "0"
+    try:
+        r = dxrs.Renderer(device=0)
+    finally:
+        if old is None:
+            os.environ.pop("PT_BEAMS", None)
+        else:
+            os.environ["PT_BEAMS"] = old
+    yield r
+    r.close()

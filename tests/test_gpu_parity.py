@@ -120,3 +120,27 @@ def test_deep_paths(dxrs, host, oracle, renderer):
     scene = host.scene(dxrs.host.SCENE_DEMO, seed=0)
     img, stats, ref, ostats = _render_both(dxrs, host, oracle, renderer, scene, 1920, 1080, 40, 1, rect=(900, 420, 128, 96), rr=False)
     assert stats.rays == ostats.rays and count_mismatch(img, ref) == 0
+
+
+@pytest.mark.parametrize("case", ["c1", "c2", "c2_spp4"])
+def test_primary_rays_through_the_bvh_without_beams(dxrs, host, oracle, renderer, renderer_no_beams, case):
+    """PT_BEAMS=0: the primary rays take the per-ray BVH traversal (what every frame did in round 1); same bits as the oracle and as the
+    beam-list frames of the default context."""
+    kind, w, h, bounces, spp, rect = {"c1": (dxrs.host.SCENE_SMALL, 256, 256, 4, 1, None), "c2": (dxrs.host.SCENE_DEMO, 1920, 1080, 8, 1, (832, 476, 256, 128)),
+                                      "c2_spp4": (dxrs.host.SCENE_DEMO, 1280, 720, 6, 4, (500, 300, 160, 96))}[case]
+    spheres, materials, sd = host.scene(kind, seed=0)
+    gs = dxrs.types.graphics_settings(w, h, frame_index=4, bounces=bounces, spp=spp)
+    cam = host.camera(w, h, jitter_index=4)
+    imgs = []
+    for r in (renderer_no_beams, renderer):
+        r.set_scene(spheres, materials, sd); r.set_camera(cam); r.set_constants(gs)
+        if r is renderer:
+            img, st = render_rested(r, rect, expect_beams=True)
+        else:
+            r.render(rect); r.render(rect)
+            img, st = r.render(rect)
+            assert st.beams_used == 0
+        imgs.append((img, st.rays))
+    ref, ost = oracle.render(spheres, materials, sd, cam, gs, rect=rect, threads=8)
+    for img, rays in imgs:
+        assert rays == ost.rays and count_mismatch(img, ref) == 0
