@@ -160,7 +160,27 @@ class _OracleOps:
         tiles.unpack_ranges(frame.numpy().reshape(self.h, self.w, 4), parts, first0, run, stride)
 
 
-def _exchange_worker(rank, world, port, w, h, out_path):
+class _OracleOpsPtGather(_OracleOps):
+    """... with the exchange going through ops.gather_parts -- the branch that calls pt_gather on the GPU.  pt_gather's contract
+    (include/pt_api.h) is emulated over gloo with raw pointers: every rank but the root sends nbytes; the root receives world - 1 parts,
+    rank r's at recv + (r - 1) * nbytes, and contributes nothing."""
+
+    def gather_parts(self, send, recv, nbytes):
+        import ctypes
+
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        mine = torch.zeros(nbytes, dtype=torch.uint8) if rank == 0 else send.contiguous().view(torch.uint8).reshape(-1)[:nbytes].clone()
+        assert mine.numel() == nbytes
+        parts = [torch.zeros(nbytes, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, parts, dst=0)
+        if rank == 0:
+            for r in range(1, world):
+                ctypes.memmove(recv.data_ptr() + (r - 1) * nbytes, parts[r].data_ptr(), nbytes)
+
+
+def _exchange_worker(rank, world, port, w, h, out_path, pt_gather=False):
     sys.path.insert(0, ROOT)
     import time
 
@@ -175,7 +195,7 @@ def _exchange_worker(rank, world, port, w, h, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ops = _OracleOps(dxrs_amd, load_oracle(), dxrs_amd.load_host(), w, h)
+    ops = (_OracleOpsPtGather if pt_gather else _OracleOps)(dxrs_amd, load_oracle(), dxrs_amd.load_host(), w, h)
     batch = 3
     results = {}
     ex_plain = TileExchange(ops, w, h, rank, world, batch, rgb=False)  # float4 records on the wire
@@ -215,16 +235,17 @@ def _exchange_worker(rank, world, port, w, h, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_batched_weighted_exchange_bit_identical(world, tmp_path):
+@pytest.mark.parametrize("world,pt_gather", [(2, False), (3, False), (2, True), (3, True)])
+def test_batched_weighted_exchange_bit_identical(world, pt_gather, tmp_path):
     """dxrs_amd.exchange.TileExchange (the code bench.py runs over RCCL) over gloo: batched gather, root-weighted
-    partitions incl. 'root renders everything', partial final batch, and the autotune protocol"""
+    partitions incl. 'root renders everything', partial final batch, and the autotune protocol -- through torch.distributed.gather
+    and through the ops.gather_parts branch (pt_gather's contract: no root contribution, parts of ranks 1.. packed from recv on)"""
     import torch.multiprocessing as mp
 
     w, h = 100, 70
     out = str(tmp_path / "ex.npy")
-    port = 31500 + (os.getpid() % 2000) + world
-    mp.spawn(_exchange_worker, args=(world, port, w, h, out), nprocs=world, join=True)
+    port = 31500 + (os.getpid() % 2000) + world + (10 if pt_gather else 0)
+    mp.spawn(_exchange_worker, args=(world, port, w, h, out, pt_gather), nprocs=world, join=True)
     res = np.load(out)
     for i in range(4):
         assert np.array_equal(res[i].view(np.uint32), res[4].view(np.uint32)), f"weight case {i}"
