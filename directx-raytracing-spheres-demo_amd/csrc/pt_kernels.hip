@@ -1046,13 +1046,26 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
     // where every WAVE pulls its next 64 entries from a work cursor (one atomic per 64 paths; no barrier inside this loop in
     // the looping form): a segment lists one workgroup's tiles top to bottom of the image, and a static stride over such a
     // queue can hand a workgroup the same image region again and again (C3: 7.2 vs 6.5 ms for the looping pass).
+    // 1 spp (kMulti = false): every wave's FIRST 64 entries are its own by position (no atomic); only what lies beyond one entry
+    // per thread of the grid is handed out by the cursor.  The host sizes the grid to the queue, so the pass makes no cursor
+    // atomics at all: 1200 waves hitting one address at launch cost 5-10 us EACH (tools/experiments/loopstamps.py: same-address
+    // device-scope atomics from 8 XCDs serialise), before the first ray and again to learn that the queue is empty -- the
+    // driver's 20-step C2 run went from 0.102-0.106 to 0.095 ms per frame.  At spp > 1 a wave draws ~30 long batches, the atomics
+    // do not show, and the extra loop state made that kernel spill (C4 +3 %): it keeps the plain cursor.
     uint32_t* const cursor = const_cast<uint32_t*>(count_in_ptr) + fc.n_counts + 1u;  // the work cursor of this queue (zeroed when the counters are folded)
     for (uint32_t base = blockIdx.x * blockDim.x;; base += gridDim.x * blockDim.x) {
         uint32_t i;
         if (seg_in) {
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(cursor, 64u);
-            b = __builtin_amdgcn_readfirstlane(b);
+            uint32_t b;
+            const uint32_t static_end = kMulti ? 0u : gridDim.x * blockDim.x;
+            if (!kMulti && base < static_end) {  // the first pass through this loop
+                b = base + wave * 64u;
+            } else {
+                if (!kMulti && static_end >= count) break;
+                uint32_t v = 0;
+                if (lane == 0) v = atomicAdd(cursor, 64u);
+                b = static_end + __builtin_amdgcn_readfirstlane(v);
+            }
             if (b >= count) break;
             i = b + lane;
         } else if (seg_out) {
