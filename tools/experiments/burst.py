@@ -20,9 +20,12 @@ bufs = [torch.empty((h * w, 4), dtype=torch.float32, device="cuda") for _ in ran
 cams = [host.camera(w, h, jitter_index=k, jitter_count=8) for k in range(8)]
 def frame(k):
     gs.FrameIndex = k; r.set_camera(cams[k % 8]); r.set_constants(gs); r.render_device(bufs[k % lanes].data_ptr())
-for k in range(40):
+n_warm = 40
+for k in range(n_warm):
     frame(k)
 torch.cuda.synchronize()
+calls = n_warm  # frame index = render-call count, so that buffer k % lanes stays on lane k % lanes in every repetition (a buffer that
+                # moves to another lane between bursts makes render_common serialise the frames: the rotation contract of pt_render)
 for rep in range(3):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
     torch.cuda.synchronize()
@@ -30,7 +33,7 @@ for rep in range(3):
     ev[0].record(ts)
     sub = []
     for k in range(n):
-        frame(100 + k)
+        frame(calls); calls += 1  # buffer = call count % lanes, the lane rotation of the renderer
         ev[k + 1].record(ts)
         sub.append(time.perf_counter() - t0)
     t_sub = time.perf_counter() - t0
