@@ -98,10 +98,12 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     if args.frames_in_flight == 0:
-        # one GPU: 3 lanes + the caller's stream = the 4 hardware queues HIP drives; small frames are bound by the dependent
-        # chain of a frame's two launches rather than by throughput and gain from 6 (256x256: 0.0217 -> 0.0170 ms, 640x384:
-        # 0.0433 -> 0.0387; 1080p and up: within 2 %, so the headline configuration keeps 3 and its per-launch figures)
-        args.frames_in_flight = 4 if (world > 1 or args.force_tiles) else (6 if args.width * args.height < 1500000 else 3)
+        # 3 lanes, which the library puts on hardware queues of their own (pt_create: highest-priority pool), so that neither the
+        # caller's stream nor the RCCL gather on it shares a queue with a lane.  Small untiled frames are bound by the dependent
+        # chain of a frame's two launches rather than by throughput and gain from 6 lanes in the default pool, as long as the
+        # process has few other streams (256x256: 0.0186 -> 0.0162 ms, 640x384: 0.0356 -> 0.0313); the tiled path is best with 3
+        # (tools/experiments/lanes_prio2.sh, tilecost.py: 1080p in tiles 0.113 ms against 0.139 with 4 default-pool lanes)
+        args.frames_in_flight = 3 if (world > 1 or args.force_tiles) else (6 if args.width * args.height < 1500000 else 3)
     nbuf = args.frames_in_flight
     r = dxrs_amd.Renderer(device=local_rank, stream=stream, frames_in_flight=nbuf)
     tex = None

@@ -40,7 +40,7 @@ struct EventPair {
 struct Knobs {
     int split = -1, traverse_blocks_per_cu = -1, fused_threads = -1, no_adaptive_grid = -1, shade_blocks_per_cu = -1, tail_threshold = -1,
         tail_blocks_per_cu = -1, loop_threads = -1, inline2_min_slots = -1, tail_after = -1, seg = -1, loop_use_tail = -1, fuse_loop = -1,
-        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1;
+        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1, lane_priority = -1;
 };
 
 // Per-frame-in-flight state (see PtContext::lanes).
@@ -440,7 +440,7 @@ Knobs read_knobs()
     k.no_adaptive_grid = std::getenv("PT_NO_ADAPTIVE_GRID") ? 1 : -1; k.shade_blocks_per_cu = env_knob("PT_SHADE_BLOCKS_PER_CU");
     k.tail_threshold = env_knob("PT_TAIL_THRESHOLD"); k.tail_blocks_per_cu = env_knob("PT_TAIL_BLOCKS_PER_CU"); k.loop_threads = env_knob("PT_LOOP_THREADS");
     k.inline2_min_slots = env_knob("PT_INLINE2_MIN_SLOTS"); k.tail_after = env_knob("PT_TAIL_AFTER"); k.seg = env_knob("PT_SEG");
-    k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
+    k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.lane_priority = env_knob("PT_LANE_PRIORITY"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
     k.dyn_blocks_per_cu = env_knob("PT_DYN_BLOCKS_PER_CU"); k.debug_counts = std::getenv("PT_DEBUG_COUNTS") ? 1 : -1; k.sah = env_knob("PT_SAH");
     k.sah_max_spheres = env_knob("PT_SAH_MAX_SPHERES"); k.beams = env_knob("PT_BEAMS"); k.wide = env_knob("PT_WIDE"); k.descent = env_knob("PT_DESCENT"); k.roctx = env_knob("PT_ROCTX");
     return k;
@@ -921,7 +921,23 @@ PtStatus pt_create(const PtConfig* config, PtContext** out_ctx)
     for (uint32_t i = 0; i < c->n_lanes; i++) {
         Lane& L = c->lanes[i];
         if (c->n_lanes == 1) L.stream = c->stream;
-        else if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
+        else {
+            // Up to three lanes get streams of the HIGHEST priority.  The runtime keeps one pool of hardware queues per priority
+            // level and hands a new stream the least-used queue of its pool, so a lane created at the default priority shares the
+            // 4 queues of that pool with every other stream of the process -- and a lane that lands on the hardware queue of the
+            // CALLER's stream sits behind the completion waits of the frames before it (in-order queue): the same C2 frame took
+            // 0.082 or 0.119 ms depending on how many streams the process had created before the context
+            // (tools/experiments/qmap.py: 0 / 1 / 2 / 6 earlier streams fast, 3 / 4 / 5 / 7 / 8 slow).  In their own pool the lanes'
+            // queues depend on nothing but their own number: 0.082 ms in all nine cases.  That pool serves three lanes well and
+            // no more (4 / 6 / 8 lanes there: 256x256 frames 0.054 instead of 0.016-0.019 ms), so more than three lanes stay in
+            // the default pool, where 6 are the best choice for small frames in a process that has few other streams.
+            // PT_LANE_PRIORITY=0 creates every lane at the default priority (A/B runs).
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = the numerically lowest value = the highest priority
+            const bool own_pool = knob_or(c->knobs.lane_priority, 1u) != 0 && hi < lo && c->n_lanes <= 3;
+            const hipError_t e = own_pool ? hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
+            if (e != hipSuccess) { pt_destroy(c); return PT_ERR_HIP; }
+        }
         bool ok = true;
         for (auto& e : L.ev_poll) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
         if (!ok || hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) != hipSuccess

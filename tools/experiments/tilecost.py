@@ -10,7 +10,7 @@ dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
 host = dxrs_amd.load_host()
 s, m, sd = host.scene(0, 0)
 W, H = 640, 384
-for lanes in (1, 4, 8):
+for lanes in ([int(a) for a in sys.argv[1:]] or [1, 4, 8]):
     ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
     r = dxrs_amd.Renderer(stream=ts.cuda_stream, frames_in_flight=lanes)
     r.set_scene(s, m, sd); r.set_partition(0, 1)
