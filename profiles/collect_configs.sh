@@ -17,6 +17,7 @@ run --steps 300 --warmup 30 --di --no-cpu-baseline                              
 run --width 3840 --height 2160 --spp 16 --steps 20 --warmup 3 --cpu-row-step 16                       # C3
 run --width 3840 --height 2160 --spp 64 --bounces 16 --steps 6 --warmup 2 --no-cpu-baseline           # C4 on one GPU
 run --scene procedural --steps 40 --warmup 5                                                          # C5
+run --steps 300 --warmup 30 --force-tiles --no-cpu-baseline --no-roofline                            # C2 through the tile path on one rank (render tiles, gather, un-swizzle)
 TAG=$TAG python3 - <<'PY'
 import json, os
 for l in open("gpurun_out/%s_configs.jsonl" % os.environ["TAG"]):
