@@ -51,8 +51,9 @@ typedef struct PtConfig {
                                legacy default (null) stream with PT_FLAG_DEFAULT_STREAM */
     uint32_t flags;         /* PT_FLAG_* */
     uint32_t frames_in_flight; /* 0 or 1: one frame at a time; 2..8: that many lanes (see PT_FLAG_TWO_FRAMES_IN_FLIGHT).  3 is the
-                                  recommended value: up to three lanes run on hardware queues of their own (streams of the highest
-                                  priority), whatever other streams the process has; more lanes share the default queues */
+                                  recommended value: up to three lanes run as streams of the highest priority, whose hardware queues
+                                  they share with nothing else unless the process creates highest-priority streams of its own; more
+                                  lanes share the default-priority queues with every other stream of the process */
 } PtConfig;
 
 enum {

@@ -1,10 +1,42 @@
 """Hash of the kernel sources: profiles/counters_*.json are stamped with it, and bench.py reports their numbers only while the
-sources they were measured on are the ones being run (committed counter files otherwise go stale silently)."""
+sources they were measured on are the ones being run (committed counter files otherwise go stale silently).
+Comments and white space do not count: the hash is taken over the token text of csrc/*.h*, csrc/*.cpp and include/*.h, so a
+reworded comment does not invalidate a measurement, any change the compiler sees does."""
 import glob
 import hashlib
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def strip_comments_and_space(src):
+    """C / C++ source without comments and white space (string and character literals are kept verbatim)."""
+    out = []
+    i, n = 0, len(src)
+    while i < n:
+        ch = src[i]
+        if ch == '"' or ch == "'":
+            j = i + 1
+            while j < n and src[j] != ch:
+                j += 2 if src[j] == "\\" else 1
+            out.append(src[i:j + 1])
+            i = j + 1
+        elif src.startswith("//", i):
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith("/*", i):
+            j = src.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            if out and not out[-1].isspace():
+                out.append(" ")
+        elif ch.isspace():
+            if out and not out[-1].isspace():
+                out.append(" ")
+            i += 1
+        else:
+            out.append(ch)
+            i += 1
+    return "".join(out)
 
 
 def kernel_source_hash():
@@ -13,7 +45,7 @@ def kernel_source_hash():
                    + glob.glob(os.path.join(ROOT, "include", "*.h")))
     for f in files:
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(strip_comments_and_space(open(f, encoding="utf-8").read()).encode())
     return h.hexdigest()[:16]
 
 
