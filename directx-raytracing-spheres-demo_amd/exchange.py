@@ -26,6 +26,7 @@ ops protocol (optional: ops.gather_parts(send, recv, nbytes) replaces torch.dist
     ops.unpack_rgb(...)                                        ops.unpack for 3-float parts (pt_unpack_tiles_rgb)
     ops.set_range(first, run, stride)                          partition of this rank (pt_set_partition_ex)
     ops.render(frame_index, out)                               this rank's range of that frame -> packed tensor `out`
+    ops.render_full(frame_index, frame)                        (optional) the whole frame, row-major, no tiles: used for root_weight 0
     ops.unpack(packed, offset_px, part_stride_px, n_parts, first0, run, stride, frame)   (pt_unpack_tiles_ex; packed = flat tensor)
 """
 import torch
@@ -66,6 +67,8 @@ class TileExchange:
         self.stride = self.range[2]
         self.n_root = tiles.range_tiles_count(self.w, self.h, *tiles.weighted_partition(0, self.world, root_weight), self.ts)
         self.sharded = self.world > 1 and root_weight != 0
+        # weight 0 with several ranks: rank 0 renders whole frames straight into self.frames (ops.render_full), the others idle
+        self.direct = self.world > 1 and root_weight == 0 and getattr(self.ops, "render_full", None) is not None
         # every non-root rank sends the same number of tiles (the first of them owns the most; later ones are zero padded)
         self.n_other = tiles.range_tiles_count(self.w, self.h, *tiles.weighted_partition(1, self.world, root_weight), self.ts) if self.sharded else 0
         n_own = self.n_root if self.rank == 0 else self.n_other
@@ -82,7 +85,11 @@ class TileExchange:
     def submit(self, frame_index):
         """queue one frame; the collective + un-swizzle are issued when its batch is complete"""
         b, slot = (self.submitted // self.batch) % 2, self.submitted % self.batch
-        if self.own_px:
+        if self.direct:
+            # "do not shard": rank 0 renders the frame where it belongs -- no tiles, no un-swizzle; the job is as fast as one GPU
+            if self.rank == 0:
+                self.ops.render_full(frame_index, self.frames[slot])
+        elif self.own_px:
             self.ops.render(frame_index, self.own[b][slot])
         self.submitted += 1
         if slot == self.batch - 1:
@@ -96,6 +103,8 @@ class TileExchange:
             self.submitted += self.batch - pending  # the next submit starts a fresh batch
 
     def _flush(self, b, n_frames):
+        if self.direct:
+            return
         if self.sharded:
             # every rank contributes the same number of bytes; rank 0's own tiles never travel (its slot carries a dummy)
             if self.rank == 0:
@@ -180,6 +189,10 @@ class HipOps:
     def render(self, k, out):
         self.set_frame(k)
         self.r.render_tiles(out.data_ptr())
+
+    def render_full(self, k, frame):
+        self.set_frame(k)
+        self.r.render_device(frame.data_ptr())
 
     def unpack(self, packed, offset_px, part_stride_px, n_parts, first0, run, stride, frame):
         self.r.unpack_tiles_ex(packed.data_ptr() + 16 * int(offset_px), int(part_stride_px), n_parts, first0, run, stride, frame.data_ptr())

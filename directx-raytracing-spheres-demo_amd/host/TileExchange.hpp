@@ -27,7 +27,7 @@ struct Range { uint32_t first, run, stride; };  // the tiles t with first <= t %
 inline uint32_t TileCount(uint32_t w, uint32_t h, uint32_t ts = 32) { return ((w + ts - 1) / ts) * ((h + ts - 1) / ts); }
 
 // rank 0 (which assembles the frame, so its tiles need no transfer) carries rootWeight shares, every other rank one;
-// rootWeight == 0: rank 0 renders everything
+// rootWeight == 0: rank 0 renders everything (with several ranks: whole frames through Backend::RenderFull, not tiles)
 inline Range WeightedPartition(uint32_t rank, uint32_t world, uint32_t rootWeight)
 {
     if (world == 1 || rootWeight == 0) return rank == 0 ? Range{ 0, 1, 1 } : Range{ 0, 0, 1 };
@@ -61,6 +61,11 @@ public:
     {
         m_setFrame(frameIndex);
         ThrowIfFailed(pt_render_tiles(m_ctx, out, nullptr), m_ctx, "pt_render_tiles");
+    }
+    void RenderFull(uint32_t frameIndex, void* frame)  // the whole frame, row-major float4: root weight 0 ("do not shard")
+    {
+        m_setFrame(frameIndex);
+        ThrowIfFailed(pt_render(m_ctx, nullptr, frame, 1, nullptr), m_ctx, "pt_render");
     }
     void PackRgb(const void* src, uint64_t nPixels, void* dst) { ThrowIfFailed(pt_pack_rgb(m_ctx, src, nPixels, dst), m_ctx, "pt_pack_rgb"); }
     void UnpackTiles(const void* packed, uint64_t partStridePx, uint32_t nParts, uint32_t first0, uint32_t run, uint32_t stride, void* frame, bool rgb)
@@ -115,6 +120,7 @@ public:
         m_rootWeight = rootWeight;
         m_range = tiles::WeightedPartition(m_rank, m_world, rootWeight);
         m_sharded = m_world > 1 && rootWeight != 0;
+        m_direct = m_world > 1 && rootWeight == 0;  // rank 0 renders whole frames straight into Frame(slot): no tiles, no un-swizzle
         m_nRoot = tiles::RangeTileCount(m_w, m_h, tiles::WeightedPartition(0, m_world, rootWeight), m_ts);
         // every non-root rank sends the same number of tiles (the first of them owns the most; later ones are zero padded)
         m_nOther = m_sharded ? tiles::RangeTileCount(m_w, m_h, tiles::WeightedPartition(1, m_world, rootWeight), m_ts) : 0;
@@ -127,7 +133,8 @@ public:
     void Submit(uint32_t frameIndex)
     {
         const uint32_t b = (m_submitted / m_batch) % 2, slot = m_submitted % m_batch;
-        if (m_ownPx) m_b.RenderTiles(frameIndex, static_cast<char*>(m_own[b]) + uint64_t(slot) * m_ownPx * 16);
+        if (m_direct) { if (m_rank == 0) m_b.RenderFull(frameIndex, m_frames[slot]); }
+        else if (m_ownPx) m_b.RenderTiles(frameIndex, static_cast<char*>(m_own[b]) + uint64_t(slot) * m_ownPx * 16);
         m_submitted++;
         if (slot == m_batch - 1) Flush(b, m_batch);
     }
@@ -150,6 +157,7 @@ public:
 private:
     void Flush(uint32_t b, uint32_t nFrames)
     {
+        if (m_direct) return;
         const uint64_t px = m_rgb ? 12 : 16;
         if (m_sharded) {
             // the whole batch buffer travels (a partial last batch leaves its tail unused): every rank sends the same byte count
@@ -182,7 +190,7 @@ private:
     void* m_send = nullptr;
     uint32_t m_rootWeight = 1, m_nRoot = 0, m_nOther = 0;
     tiles::Range m_range{ 0, 1, 1 };
-    bool m_sharded = false;
+    bool m_sharded = false, m_direct = false;
     uint64_t m_ownPx = 0, m_otherPx = 0, m_submitted = 0;
 };
 

@@ -45,6 +45,17 @@ public:
             k++;
         }
     }
+    void RenderFull(uint32_t frame, void* out)
+    {
+        float* o = static_cast<float*>(out);
+        for (uint32_t y = 0; y < m_h; y++)
+            for (uint32_t x = 0; x < m_w; x++) {
+                for (int c = 0; c < 3; c++) o[(size_t(y) * m_w + x) * 4 + c] = Pattern(x, y, frame, c);
+                o[(size_t(y) * m_w + x) * 4 + 3] = 1.0f;
+            }
+        fullFrames++;
+    }
+    uint32_t fullFrames = 0;
     void PackRgb(const void* src, uint64_t n, void* dst)
     {
         const float* s = static_cast<const float*>(src);
@@ -127,6 +138,10 @@ int RunCase(uint32_t w, uint32_t h, uint32_t world, uint32_t weight, uint32_t ba
     for (uint32_t r = world; r-- > 0;) ranks[r]->Finish();
     for (uint32_t f = 0; f < nFrames % batch; f++)
         if (Check(static_cast<const float*>(ranks[0]->Frame(f)), w, h, first + nFrames - nFrames % batch + f, what)) return 1;
+    // "do not shard" with several ranks renders whole frames on rank 0 and nothing anywhere else
+    const uint32_t wantFull = (world > 1 && weight == 0) ? nFrames : 0u;
+    for (uint32_t r = 0; r < world; r++)
+        if (backends[r]->fullFrames != (r == 0 ? wantFull : 0u)) { std::fprintf(stderr, "%s: rank %u rendered %u whole frames\n", what, r, backends[r]->fullFrames); return 1; }
     return 0;
 }
 

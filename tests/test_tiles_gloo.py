@@ -165,6 +165,12 @@ class _OracleOpsPtGather(_OracleOps):
     (include/pt_api.h) is emulated over gloo with raw pointers: every rank but the root sends nbytes; the root receives world - 1 parts,
     rank r's at recv + (r - 1) * nbytes, and contributes nothing."""
 
+    def render_full(self, k, frame):
+        """optional op: with it, root weight 0 on several ranks renders whole frames on rank 0 (no tiles, no un-swizzle)"""
+        import torch
+        frame[:] = torch.from_numpy(self.full(k).reshape(-1, 4))
+        self.full_frames = getattr(self, "full_frames", 0) + 1
+
     def gather_parts(self, send, recv, nbytes):
         import ctypes
 
@@ -227,6 +233,8 @@ def _exchange_worker(rank, world, port, w, h, out_path, pt_gather=False):
     log = {}
     chosen = ex.autotune(run_frames, dist.barrier, candidates=[1, 2, 0], log=log)
     assert chosen == 2 and ex.root_weight == 2
+    if pt_gather:  # this ops class offers render_full: weight 0 took the direct path (7 frames + the autotune's 2 x 3), on rank 0 only
+        assert getattr(ops, "full_frames", 0) == (7 + 6 if rank == 0 else 0), getattr(ops, "full_frames", 0)
     if rank == 0:
         ref = np.stack([ops.full(k) for k in range(7)])
         assert np.array_equal(results["plain"].view(np.uint32), ref[:3].view(np.uint32))
