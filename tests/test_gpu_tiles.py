@@ -204,3 +204,50 @@ def test_everything_together_tiles_textures_di_in_flight(dxrs, host, oracle):
         assert np.array_equal(got.view(np.uint32)[..., :3], ref.view(np.uint32)[..., :3]), f"frame {k}"
     for r in rs:
         r.close()
+
+
+@pytest.mark.gpu
+def test_unsharded_candidate_renders_whole_frames(dxrs, host, renderer):
+    """Root weight 0 with several ranks ("do not shard", one of the partitions bench.py's autotune tries): rank 0 renders whole frames
+    straight into the exchange's frame buffers -- no tiles, no collective, no un-swizzle -- so rank 0 of a 2-rank job can be exercised
+    here without a second rank; switching back to a sharded weight afterwards must find the buffers and the partition intact."""
+    import torch
+    from dxrs_amd.exchange import HipOps, TileExchange
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    w, h, batch = 320, 200, 3
+    cams = [host.camera(w, h, jitter_index=k) for k in range(8)]
+    gs = dxrs.types.graphics_settings(w, h, bounces=6, spp=1)
+    renderer.set_scene(spheres, materials, sd)
+    ref = []
+    for k in range(7):
+        gs.FrameIndex = k
+        renderer.set_camera(cams[k % 8]); renderer.set_constants(gs)
+        ref.append(renderer.render()[0])
+    tstream = torch.cuda.Stream()
+    r2 = dxrs.Renderer(stream=tstream.cuda_stream, frames_in_flight=3)
+    try:
+        with torch.cuda.stream(tstream):
+            r2.set_scene(spheres, materials, sd)
+
+            def set_frame(k):
+                gs.FrameIndex = k
+                r2.set_camera(cams[k % 8]); r2.set_constants(gs)
+            ex = TileExchange(HipOps(r2, torch.device("cuda", 0), set_frame), w, h, 0, 2, batch)
+            ex.configure(0)
+            assert ex.direct and not ex.sharded
+            got = []
+            for k in range(7):
+                ex.submit(k)
+                if (k + 1) % batch == 0:
+                    torch.cuda.synchronize()
+                    got += [f.cpu().numpy().reshape(h, w, 4).copy() for f in ex.frames]
+            ex.finish()
+            torch.cuda.synchronize()
+            got += [f.cpu().numpy().reshape(h, w, 4).copy() for f in ex.frames[: 7 % batch]]
+            for k in range(7):
+                assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), f"frame {k}"
+            # back to a sharded partition: rank 0's share of the tiles renders as before (the collective itself needs the other rank)
+            ex.configure(2)
+            assert ex.sharded and not ex.direct and ex.own_px == ex.n_root * 1024
+    finally:
+        r2.close()
