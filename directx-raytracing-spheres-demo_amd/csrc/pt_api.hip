@@ -40,7 +40,7 @@ struct EventPair {
 struct Knobs {
     int split = -1, traverse_blocks_per_cu = -1, fused_threads = -1, no_adaptive_grid = -1, shade_blocks_per_cu = -1, tail_threshold = -1,
         tail_blocks_per_cu = -1, loop_threads = -1, inline2_min_slots = -1, tail_after = -1, seg = -1, loop_use_tail = -1, fuse_loop = -1,
-        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1, lane_priority = -1;
+        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1, lane_priority = -1, fused_refit = -1;
 };
 
 // Per-frame-in-flight state (see PtContext::lanes).
@@ -76,6 +76,7 @@ struct Lane {
     hipEvent_t ev_poll[4] = {};       // queue-size read-backs of the last passes (spp > 1 lagged polling)
     uint32_t scene_n = 0;             // sphere count the private copy was allocated for
     bool scene_private = false;
+    bool upload_pending = false;  // h_stage holds spheres that have not been copied to d_sph yet (pt_update_spheres of a small scene: pt_refit_accel's kernel reads them)
     const void* last_out = nullptr;   // output buffer of the lane's latest frame (render_common: repeated buffers inside the window)
     // object rotations (textured scenes): the lane's own copy, refreshed from PtContext::h_rot when its generation is behind
     float4* d_rot = nullptr;
@@ -279,6 +280,7 @@ void free_lane_scene(Lane& L)
     if (L.h_stage) { (void)hipHostFree(L.h_stage); L.h_stage = nullptr; }
     L.scene_n = 0;
     L.scene_private = false;
+    L.upload_pending = false;
 }
 
 void free_lane_buffers(Lane& L)
@@ -440,7 +442,7 @@ Knobs read_knobs()
     k.no_adaptive_grid = std::getenv("PT_NO_ADAPTIVE_GRID") ? 1 : -1; k.shade_blocks_per_cu = env_knob("PT_SHADE_BLOCKS_PER_CU");
     k.tail_threshold = env_knob("PT_TAIL_THRESHOLD"); k.tail_blocks_per_cu = env_knob("PT_TAIL_BLOCKS_PER_CU"); k.loop_threads = env_knob("PT_LOOP_THREADS");
     k.inline2_min_slots = env_knob("PT_INLINE2_MIN_SLOTS"); k.tail_after = env_knob("PT_TAIL_AFTER"); k.seg = env_knob("PT_SEG");
-    k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.lane_priority = env_knob("PT_LANE_PRIORITY"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
+    k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.lane_priority = env_knob("PT_LANE_PRIORITY"); k.fused_refit = env_knob("PT_FUSED_REFIT"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
     k.dyn_blocks_per_cu = env_knob("PT_DYN_BLOCKS_PER_CU"); k.debug_counts = std::getenv("PT_DEBUG_COUNTS") ? 1 : -1; k.sah = env_knob("PT_SAH");
     k.sah_max_spheres = env_knob("PT_SAH_MAX_SPHERES"); k.beams = env_knob("PT_BEAMS"); k.wide = env_knob("PT_WIDE"); k.descent = env_knob("PT_DESCENT"); k.roctx = env_knob("PT_ROCTX");
     return k;
@@ -560,6 +562,17 @@ PtStatus beam_cache_lookup(PtContext* c, const PixelMap& pm, const uint32_t** li
     return PT_OK;  // this frame still traverses; the next ones of this view find the lists
 }
 
+// pt_update_spheres of a small scene leaves the new spheres in the lane's pinned staging buffer for pt_refit_accel's kernel to read;
+// when no refit follows, the render call uploads them as before.
+static hipError_t flush_pending_upload(PtContext* c, Lane& L)
+{
+    if (!L.upload_pending) return hipSuccess;
+    L.upload_pending = false;
+    hipError_t e = hipMemcpyAsync(L.d_sph, L.h_stage, (size_t)c->n * sizeof(float4), hipMemcpyHostToDevice, L.stream);
+    if (e == hipSuccess) e = hipEventRecord(L.ev_upload, L.stream);
+    return e;
+}
+
 // The per-frame launch sequence.  out: device float4 buffer addressed by PixelRef::out_index.
 //
 // Fused schedule (default):  bounce<primary> -> bounce (x S) -> bounce<loop>
@@ -617,6 +630,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     PtStatus st = ensure_buffers(c, L, split ? pm.n_slots : std::max<size_t>(pm.n_slots, seg_total), spp > 1, split, wf_cap + 2, di);
     if (st != PT_OK) return st;
     if ((st = sync_lane_rotations(c, L)) != PT_OK) return st;
+    PT_HIP(c, flush_pending_upload(c, L));  // pt_update_spheres without pt_refit_accel: the spheres still reach the device
     c->last_lane = c->next_lane;
     c->next_lane = (c->next_lane + 1) % c->n_lanes;
     // Primary beams: use the cached candidate lists when this frame's view is the one they were built for; start a build
@@ -1033,7 +1047,7 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
     c->accel_valid = false;
     c->scene_gen++;
     free_textures(c);  // texture maps are per sphere: a new scene starts untextured
-    for (auto& L : c->lanes) L.scene_private = false;  // every lane renders the new master scene
+    for (auto& L : c->lanes) { L.scene_private = false; L.upload_pending = false; }  // every lane renders the new master scene
     return PT_OK;
 }
 
@@ -1157,10 +1171,15 @@ PtStatus pt_update_spheres(PtContext* c, const PtSphere* spheres, uint32_t n)
     }
     c->scene_gen++;
     std::memcpy(L.h_stage, spheres, (size_t)n * sizeof(PtSphere));
+    // Small scenes: no copy here -- pt_refit_accel's single kernel reads the staging buffer (pinned host memory) itself, so a frame of
+    // an animated scene starts with ONE launch instead of a copy and four launches (DESIGN row N2).  A render call without a refit in
+    // between still uploads (flush_pending_upload).
+    if (lbvh_gpu_refit_fused_possible(n) && knob_or(c->knobs.fused_refit, 1u) != 0) { L.upload_pending = true; return PT_OK; }
     PT_HIP(c, hipMemcpyAsync(L.d_sph, L.h_stage, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, L.stream));
     PT_HIP(c, hipEventRecord(L.ev_upload, L.stream));
     return PT_OK;
 }
+
 
 PtStatus pt_refit_accel(PtContext* c)
 {
@@ -1169,6 +1188,13 @@ PtStatus pt_refit_accel(PtContext* c)
     if (!c->accel_valid || !L.scene_private) return fail(c, PT_ERR_STATE, "pt_refit_accel: call pt_update_spheres first");
     const RoctxRange range(c, "pt_refit_accel");
     PT_HIP(c, hipSetDevice(c->device));
+    if (L.upload_pending) {
+        L.upload_pending = false;
+        PT_HIP(c, lbvh_gpu_refit_fused(c->gpu_builder, reinterpret_cast<const float4*>(L.h_stage), L.d_sph, c->n, reinterpret_cast<PtBvhNode*>(L.d_nodes), L.d_sph_sorted,
+                                       c->d_sorted_id, L.d_refit_hdr, L.stream));
+        PT_HIP(c, hipEventRecord(L.ev_upload, L.stream));  // the staging buffer has been read once this kernel is done
+        return PT_OK;
+    }
     PT_HIP(c, lbvh_gpu_refit(c->gpu_builder, L.d_sph, c->n, reinterpret_cast<PtBvhNode*>(L.d_nodes), L.d_sph_sorted, c->d_sorted_id,
                              L.d_refit_flags, L.d_refit_hdr, c->depth, L.stream));
     return PT_OK;

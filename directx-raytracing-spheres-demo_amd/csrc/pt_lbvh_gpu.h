@@ -37,6 +37,12 @@ hipError_t lbvh_gpu_adopt(LbvhGpu* b, const float4* d_sph, uint32_t n, const PtB
 hipError_t lbvh_gpu_refit(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode* d_nodes, float4* d_sorted, const uint32_t* d_sorted_id,
                           uint32_t* d_flags, uint32_t* d_hdr, uint32_t depth, hipStream_t stream);
 
+// Small scenes (lbvh_gpu_refit_fused_possible): upload + bounds + gather + refit in ONE launch.  src: the new spheres as the device sees
+// them (device memory, or pinned host memory); d_sph: the device array they are copied to.
+bool lbvh_gpu_refit_fused_possible(uint32_t n);
+hipError_t lbvh_gpu_refit_fused(LbvhGpu* b, const float4* src, float4* d_sph, uint32_t n, PtBvhNode* d_nodes, float4* d_sorted, const uint32_t* d_sorted_id,
+                                uint32_t* d_hdr, hipStream_t stream);
+
 // 4-wide, quantised view of a finished binary tree (n_nodes internal nodes): d_wide = n_nodes * 4 float4 (64-byte records at the
 // binary node's index; only even-depth nodes are written / reachable).  Asynchronous on `stream`.
 hipError_t lbvh_gpu_collapse4(const PtBvhNode* d_nodes, uint32_t n_nodes, float4* d_wide, hipStream_t stream);

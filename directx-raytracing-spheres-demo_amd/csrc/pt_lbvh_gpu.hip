@@ -243,6 +243,71 @@ __global__ __launch_bounds__(kRefitSmall) void refit_small_kernel(const float4* 
     if (i == 0) hdr[12] = s_level[0];  // tree depth = the pass that completed the root
 }
 
+// The whole per-frame update of a small scene (n <= kRefitSmall) in ONE launch: the new spheres are read from `src` -- which may be
+// the caller's pinned staging buffer in host memory -- and copied to the device array the shading reads (`sph_copy`), the scene bounds
+// are reduced in LDS, the Morton-ordered copy is gathered, and the boxes are refitted bottom-up as in refit_small_kernel (the leaves
+// come from LDS: `sorted` is written by this very workgroup).  Replaces upload + init_header + bounds + gather + refit_small: five
+// dependent operations at the head of every frame of an animated scene.  Same arithmetic, same results.
+__global__ __launch_bounds__(kRefitSmall) void refit_fused_small_kernel(const float4* src, float4* __restrict__ sph_copy, const uint32_t* __restrict__ sorted_id,
+                                                                        float4* __restrict__ sorted, int n, PtBvhNode* nodes, uint32_t* hdr)
+{
+    __shared__ uint32_t s_level[kRefitSmall];
+    __shared__ float4 s_sph[kRefitSmall];
+    __shared__ float4 s_sorted[kRefitSmall];
+    __shared__ uint32_t s_hdr[16];
+    const int i = threadIdx.x;
+    if (i < 12) s_hdr[i] = ((i / 3) & 1) ? 0u : 0xFFFFFFFFu;  // init_header_kernel
+    float v[12];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { v[a] = INFINITY; v[3 + a] = -INFINITY; v[6 + a] = INFINITY; v[9 + a] = -INFINITY; }
+    if (i < n) {
+        const float4 sp = src[i];
+        s_sph[i] = sp;
+        sph_copy[i] = sp;
+        const float c[3] = { sp.x, sp.y, sp.z };
+#pragma unroll
+        for (int a = 0; a < 3; a++) { v[a] = c[a]; v[3 + a] = c[a]; v[6 + a] = c[a] - sp.w; v[9 + a] = c[a] + sp.w; }  // bounds_kernel
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const bool is_min = (k / 3) % 2 == 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o = __shfl_down(v[k], off, 64);
+            v[k] = is_min ? fminf(v[k], o) : fmaxf(v[k], o);
+        }
+    }
+    __syncthreads();  // s_hdr initialised, s_sph complete
+    if ((i & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            if ((k / 3) % 2 == 0) atomicMin(&s_hdr[k], f2ord(v[k])); else atomicMax(&s_hdr[k], f2ord(v[k]));
+        }
+    }
+    if (i < n) { const float4 g = s_sph[sorted_id[i]]; s_sorted[i] = g; sorted[i] = g; }  // gather_by_id_kernel
+    const bool is_node = i < n - 1;
+    int c0 = 0, c1 = 0;
+    if (is_node) { c0 = nodes[i].child0; c1 = nodes[i].child1; }
+    s_level[i] = 0xFFFFFFFFu;
+    __syncthreads();  // bounds reduced, s_sorted complete
+    if (i < 12) hdr[i] = s_hdr[i];
+    const float pad = refit_padding(s_hdr);
+    bool done = !is_node;
+    for (uint32_t pass = 1; pass <= 64u; pass++) {
+        if (!done) {
+            const bool r0 = c0 < 0 || s_level[c0] < pass, r1 = c1 < 0 || s_level[c1] < pass;
+            if (r0 && r1) {
+                write_node_boxes(s_sorted, nodes, i, c0, c1, pad);
+                s_level[i] = pass;
+                done = true;
+            }
+        }
+        __syncthreads();
+        if (s_level[0] != 0xFFFFFFFFu) break;
+    }
+    if (i == 0) hdr[12] = s_level[0];
+}
+
 __global__ void refit_pass_kernel(const float4* __restrict__ sorted, int n, PtBvhNode* nodes, uint32_t* level, uint32_t pass,
                                   const uint32_t* __restrict__ hdr_ro)
 {
@@ -450,6 +515,18 @@ hipError_t lbvh_gpu_refit(LbvhGpu* b, const float4* d_sph, uint32_t n, PtBvhNode
     hipLaunchKernelGGL(bounds_kernel, dim3(red_grid), dim3(threads), 0, stream, d_sph, n, d_hdr);  // the padding follows the new bounds
     hipLaunchKernelGGL(gather_by_id_kernel, dim3(grid), dim3(threads), 0, stream, d_sph, d_sorted_id, n, d_sorted);
     LB_CK(launch_refit(d_sorted, n, d_nodes, d_flags, d_hdr, depth, stream));
+    return hipGetLastError();
+}
+
+bool lbvh_gpu_refit_fused_possible(uint32_t n) { return n > 1 && n <= (uint32_t)kRefitSmall; }
+
+// lbvh_gpu_refit for small scenes with the upload folded in: src = the new spheres (device memory or pinned host memory as the device
+// sees it), d_sph = the device array they are copied to
+hipError_t lbvh_gpu_refit_fused(LbvhGpu* b, const float4* src, float4* d_sph, uint32_t n, PtBvhNode* d_nodes, float4* d_sorted, const uint32_t* d_sorted_id,
+                                uint32_t* d_hdr, hipStream_t stream)
+{
+    if (!b || !src || !d_sph || !lbvh_gpu_refit_fused_possible(n) || !d_sorted || !d_sorted_id || !d_hdr || n > b->cap) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(refit_fused_small_kernel, dim3(1), dim3(kRefitSmall), 0, stream, src, d_sph, d_sorted_id, d_sorted, (int)n, d_nodes, d_hdr);
     return hipGetLastError();
 }
 
