@@ -177,6 +177,60 @@ def test_animated_scene_refit_matches_oracle(dxrs, host, oracle, flags):
         r.close()
 
 
+@pytest.mark.parametrize("n", [2, 3, 65, 1024, 1025, 1500])  # sphere counts incl. the ground: 1024 is the last single-launch size
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_moved_spheres_single_launch_refit(dxrs, host, oracle, n, fused, monkeypatch):
+    """Row N2 for small scenes: pt_update_spheres leaves the new spheres in the lane's pinned staging buffer and pt_refit_accel's ONE kernel
+    (refit_fused_small_kernel, n <= 1024) copies them, reduces the bounds, gathers and refits; PT_FUSED_REFIT=0 and larger scenes take the
+    copy + separate kernels.  Frames of moved spheres equal the oracle on the moved positions either way, over three lanes, and a render call
+    that follows an update WITHOUT a refit still sees the new spheres (here: unmoved ones, so the old boxes stay valid)."""
+    import torch
+    monkeypatch.setenv("PT_FUSED_REFIT", fused)
+    spheres0, materials, sd = host.scene(dxrs.host.SCENE_PROCEDURAL, seed=5, count=n - 1)  # n - 1 spheres + the ground (last)
+    assert len(spheres0) == n and spheres0["r"][-1] == 50.0
+    w, h = 160, 96
+    rng = np.random.default_rng(n)
+    # into the camera's view: a 10 x 10 patch of the ground around the origin
+    m = n - 1
+    spheres0["r"][:m] = rng.uniform(0.1, 0.35, m).astype(np.float32)
+    spheres0["cx"][:m] = rng.uniform(-5, 5, m).astype(np.float32)
+    spheres0["cz"][:m] = rng.uniform(-5, 5, m).astype(np.float32)
+    spheres0["cy"][:m] = (-0.1 + spheres0["r"][:m] + rng.uniform(0, 1, m)).astype(np.float32)
+    tstream = torch.cuda.Stream()
+    r = dxrs.Renderer(stream=tstream.cuda_stream, frames_in_flight=3)
+    try:
+        with torch.cuda.stream(tstream):
+            r.set_scene(spheres0, materials, sd)
+            bufs = [torch.empty((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(3)]
+            moved, frames = [], []
+            for k in range(5):
+                sph = spheres0.copy()
+                if k != 3:  # frame 3: the original positions again, uploaded without a refit right after a refit to the same positions
+                    sph["cx"][:m] += rng.uniform(-0.3, 0.3, m).astype(np.float32)
+                    sph["cy"][:m] += rng.uniform(0.0, 0.5, m).astype(np.float32)
+                    sph["r"][:m] *= rng.uniform(0.7, 1.2, m).astype(np.float32)
+                    r.update_spheres(sph)
+                else:
+                    r.update_spheres(sph)                 # boxes refitted to the original positions ...
+                    r.set_camera(host.camera(w, h, jitter_index=k)); r.set_constants(dxrs.types.graphics_settings(w, h, frame_index=k, bounces=4, spp=1))
+                    r.render_device(bufs[0].data_ptr())   # (three calls, so that the update below lands on the same lane)
+                    r.render_device(bufs[1].data_ptr())
+                    r.render_device(bufs[2].data_ptr())
+                    r.update_spheres(sph, refit=False)    # ... and the same spheres again, no refit: the render call uploads them
+                moved.append(sph)
+                gs = dxrs.types.graphics_settings(w, h, frame_index=k, bounces=4, spp=1)
+                r.set_camera(host.camera(w, h, jitter_index=k)); r.set_constants(gs)
+                r.render_device(bufs[k % 3].data_ptr())
+                frames.append(bufs[k % 3].clone())
+            torch.cuda.synchronize()
+        for k in range(5):
+            gs = dxrs.types.graphics_settings(w, h, frame_index=k, bounces=4, spp=1)
+            ref, _ = oracle.render(moved[k], materials, sd, host.camera(w, h, jitter_index=k), gs, threads=8)
+            assert np.array_equal(frames[k].cpu().numpy().view(np.uint32)[..., :3], ref.view(np.uint32)[..., :3]), f"frame {k}"
+    finally:
+        r.close()
+
+
 @pytest.mark.parametrize("w,h,spp,bounces,lanes", [(1920, 1080, 1, 8, 1), (1920, 1080, 1, 8, 3), (1280, 720, 4, 6, 2), (333, 211, 1, 3, 1), (640, 360, 2, 1, 1)])
 def test_segmented_and_dense_hand_over_agree(dxrs, host, w, h, spp, bounces, lanes, monkeypatch):
     """the queue between the primary pass and the looping pass is segmented per workgroup by default (no barrier, no global
