@@ -80,13 +80,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # PT_BENCH_REHEARSAL=1: every rank on GPU 0, process group over gloo, the tile exchange staged through the host -- a rehearsal of this
+    # script's N > 1 control flow (autotune, batches, barriers, totals) on a one-GPU box, where RCCL refuses ("Duplicate GPU detected").
+    # Its numbers mean nothing (the ranks share one GPU) and the line says so.
+    rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     tiled = world > 1 or args.force_tiles
     if tiled:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     host = dxrs_amd.load_host()
     kind = {"demo": dxrs_amd.host.SCENE_DEMO, "small": dxrs_amd.host.SCENE_SMALL, "procedural": dxrs_amd.host.SCENE_PROCEDURAL}[args.scene]
@@ -142,10 +151,14 @@ def main():
         # The exchange itself: the C-ABI's pt_gather (RCCL grouped send/recv behind include/pt_api.h -- what a C++ host uses),
         # verified on the live job with a known pattern before it is trusted; torch.distributed.gather otherwise.
         cabi = False
-        if args.gather == "cabi" and world > 1:
+        if args.gather == "cabi" and world > 1 and not rehearsal:
             cabi = init_cabi_gather(r, dist, torch, dev, rank, world)
-        ex = TileExchange(HipOps(r, dev, set_frame, cabi_gather=cabi), w, h, rank, world, batch, rehearse=args.force_tiles and world == 1)
-        gather_kind = "pt_gather (C-ABI, RCCL send/recv)" if cabi else "torch.distributed.gather (RCCL)"
+        ops = HipOps(r, dev, set_frame, cabi_gather=cabi)
+        if rehearsal and world > 1:
+            ops.gather_parts = lambda send, recv, nbytes: staged_gather(torch, dist, rank, world, send, recv, nbytes)
+        ex = TileExchange(ops, w, h, rank, world, batch, rehearse=args.force_tiles and world == 1)
+        gather_kind = ("gloo, staged through the host (PT_BENCH_REHEARSAL: all ranks on one GPU, timings meaningless)" if rehearsal else
+                       "pt_gather (C-ABI, RCCL send/recv)" if cabi else "torch.distributed.gather (RCCL)")
     if args.animate:
         if args.scene != "demo":
             raise SystemExit("--animate is defined for the demo scene")
@@ -243,6 +256,7 @@ def main():
                             + (f", 32x32 tiles interleaved over {world} GPU(s) + RCCL gather to rank 0" if tiled else ""),
                 **({"tile_exchange": {"gather": gather_kind, "root_weight": ex.root_weight, "frames_per_gather": ex.batch, "root_tiles": ex.n_root,
                                       "tiles_per_other_rank": ex.n_other, "autotune": tune_log or None}} if tiled else {}),
+                **({"rehearsal": "PT_BENCH_REHEARSAL=1: all ranks on ONE GPU over gloo -- control-flow rehearsal, not a measurement"} if rehearsal else {}),
                 "frames_in_flight": args.frames_in_flight,
                 "animated": bool(args.animate),
                 "rays_per_frame": rays / args.steps,
@@ -409,6 +423,19 @@ def roofline_object(args, w, h, world, tiled, prof, tot_ev, qs, elapsed, elapsed
                    "'traffic' is the measured HBM bytes per launch (far below: the fused kernels keep rays in registers), 'valu' the instruction-issue bound "
                    "that binds; with N frames in flight launches of consecutive frames overlap and stretch ('exclusive' = one frame at a time)")
     return out
+
+
+def staged_gather(torch, dist, rank, world, send, recv, nbytes):
+    """pt_gather's contract (include/pt_api.h: every rank but the root sends nbytes, rank r's part lands at recv + (r - 1) * nbytes, the
+    root contributes nothing) over gloo with host staging -- PT_BENCH_REHEARSAL only."""
+    mine = torch.zeros(nbytes, dtype=torch.uint8) if rank == 0 else send.contiguous().view(torch.uint8).reshape(-1)[:nbytes].cpu()
+    parts = [torch.zeros(nbytes, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, parts, dst=0)
+    if rank == 0:
+        store = torch.empty(0, dtype=torch.uint8, device=recv.device).set_(recv.untyped_storage())
+        base = recv.storage_offset() * recv.element_size()
+        for q in range(1, world):
+            store[base + (q - 1) * nbytes: base + q * nbytes].copy_(parts[q])
 
 
 def init_cabi_gather(r, dist, torch, dev, rank, world):

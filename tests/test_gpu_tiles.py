@@ -251,3 +251,28 @@ def test_unsharded_candidate_renders_whole_frames(dxrs, host, renderer):
             assert ex.sharded and not ex.direct and ex.own_px == ex.n_root * 1024
     finally:
         r2.close()
+
+
+def test_bench_control_flow_with_two_ranks():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), rehearsed on ONE GPU: RCCL refuses two
+    ranks on a GPU, so PT_BENCH_REHEARSAL=1 puts the process group on gloo and stages the tile exchange through the host.  Everything else
+    is the real thing -- HIP renderer, partition autotune over every candidate, batched submit / finish, barriers, totals, the one JSON
+    line.  (The numbers of such a run mean nothing; the line says so.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PT_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + os.getpid() % 300
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--width", "640", "--height", "384"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "strong"
+    tx = d["config"]["tile_exchange"]
+    assert tx["autotune"]["chosen"] in tx["autotune"]["candidates"] and len(tx["autotune"]["seconds"]) == len(tx["autotune"]["candidates"])
+    assert "rehearsal" in d["config"] and d["roofline"]["bound"] == "hbm"
