@@ -706,7 +706,9 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     // in registers (bounce_kernel kInline2) and the looping kernel follows it directly -- two launches per frame: 4-10 % faster at
     // every frame size from 256x256 to 4K (PT_INLINE2_MIN_SLOTS switches it off below a slot count, for A/B runs).
     const bool inline2 = !split && spp == 1 && pm.n_slots >= knob_or(c->knobs.inline2_min_slots, 0u);
-    const size_t tail_after = knob_or(c->knobs.tail_after, split ? 3 : (inline2 ? 0 : 1));
+    // (split: 4 queue passes and 4 persistent workgroups per CU for the ray-replacement kernel, re-measured in round 2 after the bounded
+    // descent made these scenes VALU-bound -- 5 000 spheres 0.469 -> 0.436 ms, 2^20 2.42 -> 2.31, 4 M 5.19 -> 3.91; 10^5: 0.880 -> 0.901)
+    const size_t tail_after = knob_or(c->knobs.tail_after, split ? 4 : (inline2 ? 0 : 1));
     const uint32_t tail_threshold = knob_or(c->knobs.tail_threshold, 262144);  // queue size below which spp > 1 switches to it
 
     const bool timed = stats != nullptr;
@@ -815,7 +817,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
                 if (!c->lds_scene && sv.n > 1 && knob_or(c->knobs.ray_replacement, 1)) {
                     // persistent waves with ray replacement (heavy-tailed visit counts of large scenes)
                     uint32_t* cursor = counts + L.cap_counts + k + 1;
-                    const uint32_t grid = std::min(grid_for(estimate(k + 1), 256u, c->num_cus * 8u), c->num_cus * knob_or(c->knobs.dyn_blocks_per_cu, 6));
+                    const uint32_t grid = std::min(grid_for(estimate(k + 1), 256u, c->num_cus * 8u), c->num_cus * knob_or(c->knobs.dyn_blocks_per_cu, 4));
                     PT_HIP(c, bracket(1, [&] { return launch_traverse_dyn(sv, qout, counts + k + 1, cursor, fc.totals, grid, L.stream); }));
                 } else {
                     PT_HIP(c, bracket(1, [&] { return launch_traverse(sv, qout, counts + k + 1, grid_for(estimate(k + 1), trav_threads, trav_cap), L.stream); }));
