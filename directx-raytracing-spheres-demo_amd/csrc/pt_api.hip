@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "../../include/pt_api.h"
@@ -146,6 +147,7 @@ struct PtContext {
     uint32_t last_lane = 0;
     hipEvent_t ev_in[kMaxLanes] = {};  // markers on `stream` at the start of the last n_lanes render calls
     uint64_t calls = 0;
+    bool empty_scene = false;  // pt_set_scene(n = 0): one internal sphere that no ray can hit stands in (see pt_set_scene)
     float4* d_out = nullptr;
     size_t cap_out = 0;
     uint64_t tot_pixels = 0, tot_paths = 0, tot_fixed_bytes = 0, tot_sec_coeff = 96;  // host-known parts of the totals
@@ -1006,9 +1008,18 @@ const char* pt_last_error(PtContext* c) { return c ? c->err.c_str() : "null cont
 PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* materials, uint32_t n, const PtSceneData* sd)
 {
     if (!c) return PT_ERR_INVALID_ARG;
-    if (!spheres || !materials || !sd || n == 0) return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: null pointer or n == 0");
+    if (!sd || (n != 0 && (!spheres || !materials))) return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: null pointer");
     if (n > (1u << 30)) return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: too many spheres");
-    for (uint32_t i = 0; i < n; i++)
+    // An EMPTY scene is legal (a TLAS without instances: every ray misses, every pixel is the environment).  Inside, one sphere with a
+    // NaN centre stands in: intersect_sphere's comparisons are all false for it, so no ray can hit it whatever its tmax, and the
+    // single-sphere path of closest_hit has no tree that could look at its bounds.
+    const bool empty = n == 0;
+    const PtSphere nan_sphere{ std::numeric_limits<float>::quiet_NaN(), std::numeric_limits<float>::quiet_NaN(), std::numeric_limits<float>::quiet_NaN(), 1.0f };
+    PtMaterial blank_material{};
+    blank_material.IOR = 1.0f;
+    if (empty) { spheres = &nan_sphere; materials = &blank_material; n = 1; }
+    c->empty_scene = empty;
+    for (uint32_t i = 0; i < n && !empty; i++)
         if (!(spheres[i].r > 0.0f) || !std::isfinite(spheres[i].r) || !std::isfinite(spheres[i].cx) || !std::isfinite(spheres[i].cy) || !std::isfinite(spheres[i].cz))
             return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: sphere " + std::to_string(i) + " has a non-finite centre or non-positive radius");
     PT_HIP(c, hipSetDevice(c->device));
@@ -1128,11 +1139,11 @@ PtStatus pt_build_accel(PtContext* c, PtAccelInfo* info)
     c->scene_gen++;
     if (info) {
         std::memset(info, 0, sizeof *info);
-        info->leaf_count = n;
+        info->leaf_count = c->empty_scene ? 0u : n;
         info->node_count = c->n_nodes;
         info->depth = c->depth;
         info->lds_resident = c->lds_scene ? 1u : 0u;
-        for (int a = 0; a < 3; a++) { info->bounds_min[a] = c->lbvh.bounds_min[a]; info->bounds_max[a] = c->lbvh.bounds_max[a]; }
+        for (int a = 0; a < 3; a++) { info->bounds_min[a] = c->empty_scene ? 0.0f : c->lbvh.bounds_min[a]; info->bounds_max[a] = c->empty_scene ? 0.0f : c->lbvh.bounds_max[a]; }
         info->build_ms = build_ms;
         info->builder = builder_kind;
     }
@@ -1142,6 +1153,8 @@ PtStatus pt_build_accel(PtContext* c, PtAccelInfo* info)
 PtStatus pt_update_spheres(PtContext* c, const PtSphere* spheres, uint32_t n)
 {
     if (!c) return PT_ERR_INVALID_ARG;
+    if (c->empty_scene && n == 0 && c->scene_set) return PT_OK;  // nothing to move
+    if (c->empty_scene) return fail(c, PT_ERR_INVALID_ARG, "pt_update_spheres: the sphere count must not change (the scene is empty; use pt_set_scene)");
     if (!spheres) return fail(c, PT_ERR_INVALID_ARG, "pt_update_spheres: null pointer");
     if (!c->scene_set || !c->accel_valid) return fail(c, PT_ERR_STATE, "pt_update_spheres: pt_set_scene + pt_build_accel first");
     if (n != c->n) return fail(c, PT_ERR_INVALID_ARG, "pt_update_spheres: the sphere count must not change (use pt_set_scene)");
@@ -1186,6 +1199,7 @@ PtStatus pt_update_spheres(PtContext* c, const PtSphere* spheres, uint32_t n)
 PtStatus pt_refit_accel(PtContext* c)
 {
     if (!c) return PT_ERR_INVALID_ARG;
+    if (c->empty_scene && c->accel_valid) return PT_OK;  // no boxes
     Lane& L = c->lanes[c->next_lane];
     if (!c->accel_valid || !L.scene_private) return fail(c, PT_ERR_STATE, "pt_refit_accel: call pt_update_spheres first");
     const RoctxRange range(c, "pt_refit_accel");
@@ -1400,7 +1414,7 @@ PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_tex
         uint32_t any = 0;
         for (uint32_t k = 0; k < PT_TEXTURE_MAP_COUNT; k++) {
             const PtTextureMapInfo none{ ~0u, 0u, { 0u, 0u } };
-            const PtTextureMapInfo& mi = object_textures ? object_textures[i].Maps[k] : none;
+            const PtTextureMapInfo& mi = (object_textures && !c->empty_scene) ? object_textures[i].Maps[k] : none;
             if (mi.Descriptor != ~0u) {
                 if (mi.Descriptor >= n_textures) return fail(c, PT_ERR_INVALID_ARG, "pt_set_textures: Descriptor out of range");
                 if (mi.TextureCoordinateIndex != 0) return fail(c, PT_ERR_UNSUPPORTED, "pt_set_textures: spheres have one texture-coordinate set (index 0)");
@@ -1440,7 +1454,7 @@ PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_tex
     PT_HIP(c, hipMalloc(&c->d_rot, (size_t)n * sizeof(float4)));
     c->h_rot.assign((size_t)n, make_float4(0.f, 0.f, 0.f, 1.f));
     if (rotations)
-        for (uint32_t i = 0; i < n; i++) c->h_rot[i] = make_float4(rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]);
+        for (uint32_t i = 0; i < n && !c->empty_scene; i++) c->h_rot[i] = make_float4(rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]);
     PT_HIP(c, hipMemcpy(c->d_rot, c->h_rot.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));  // (everything was synchronised above)
     c->rot_master_gen = ++c->rot_gen;  // the master copy is current; lanes take private copies from the next pt_update_rotations on
     c->has_textures = true;
@@ -1451,6 +1465,7 @@ PtStatus pt_update_rotations(PtContext* c, const float* rotations, uint32_t n)
 {
     if (!c) return PT_ERR_INVALID_ARG;
     if (!c->has_textures) return fail(c, PT_ERR_STATE, "pt_update_rotations: the scene has no textures (rotations only orient texture coordinates)");
+    if (c->empty_scene) return n == 0 ? PT_OK : fail(c, PT_ERR_INVALID_ARG, "pt_update_rotations: count differs from the scene's sphere count");
     if (n != c->n) return fail(c, PT_ERR_INVALID_ARG, "pt_update_rotations: count differs from the scene's sphere count");
     // No device work and no wait here: the frames in flight keep the rotations they were submitted with; every later render
     // call uploads these into its lane's own copy on its own stream (sync_lane_rotations), like pt_update_spheres does.

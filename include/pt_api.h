@@ -116,7 +116,8 @@ typedef struct PtBvhNode {
 PtStatus pt_create(const PtConfig *config, PtContext **out_ctx);
 void pt_destroy(PtContext *ctx);
 
-/* Copies n spheres + n materials (material i belongs to sphere i == ObjectIndex) and the scene constants. */
+/* Copies n spheres + n materials (material i belongs to sphere i == ObjectIndex) and the scene constants.  n == 0 is a legal scene
+ * (a TLAS without instances; the pointers may be NULL): every ray misses and every pixel is the environment. */
 PtStatus pt_set_scene(PtContext *ctx, const PtSphere *spheres, const PtMaterial *materials, uint32_t n,
                       const PtSceneData *scene_data);
 /* Builds the LBVH over the current spheres.  info may be NULL. */

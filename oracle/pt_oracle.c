@@ -1335,7 +1335,7 @@ static void *worker(void *arg)
 
 static int validate(const PtSceneData *sd, const PtGraphicsSettings *gs, uint32_t n)
 {
-    if (n == 0) return 1;
+    (void)n; /* n == 0 is a legal scene: a TLAS without instances -- every ray misses, every pixel is the environment */
     if (gs->RenderSize[0] == 0 || gs->RenderSize[1] == 0 || gs->SamplesPerPixel == 0) return 2;
     if (gs->RenderSize[0] > 65535u || gs->RenderSize[1] > 65535u) return 2; /* (px<<16)|py seed */
     if (gs->Denoiser) return 3;

@@ -358,3 +358,59 @@ def test_same_output_buffer_on_consecutive_frames_in_flight(dxrs, host):
             assert np.array_equal(snap[k].cpu().numpy().view(np.uint32), want[k].view(np.uint32)), f"frame {k}"
     finally:
         r.close(); ref.close()
+
+
+def test_empty_scene(dxrs, host, oracle):
+    """pt_set_scene with n = 0 (the reference's TLAS may hold no instance): every pixel is the environment, bit-identical to the oracle's
+    empty scene -- plain, with several samples, in tiles, with a lat-long environment map, with frames in flight; moving "all zero"
+    spheres is a no-op, moving one is refused; a real scene afterwards renders as ever."""
+    import torch
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    w, h = 200, 120
+    tstream = torch.cuda.Stream()
+    r = dxrs.Renderer(stream=tstream.cuda_stream, frames_in_flight=3)
+    try:
+        with torch.cuda.stream(tstream):
+            info = r.set_scene(spheres[:0], materials[:0], sd)
+            assert info.leaf_count == 0 and info.node_count == 0
+            for k, (spp, bounces) in enumerate(((1, 8), (3, 4), (1, 0))):
+                gs = dxrs.types.graphics_settings(w, h, frame_index=k, bounces=bounces, spp=spp)
+                cam = host.camera(w, h, jitter_index=k)
+                r.set_camera(cam); r.set_constants(gs)
+                img, st = r.render()
+                ref, ost = oracle.render(spheres[:0], materials[:0], sd, cam, gs, threads=4)
+                assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and st.rays == ost.rays == w * h
+            r.update_spheres(spheres[:0])  # nothing to move
+            with pytest.raises(dxrs.PtError):
+                r.update_spheres(spheres[:1])
+            # tiles: rank 1 of 3 renders its tiles of the empty scene
+            from dxrs_amd import tiles
+            gs = dxrs.types.graphics_settings(w, h, frame_index=5, bounces=8, spp=1)
+            cam = host.camera(w, h, jitter_index=5)
+            r.set_camera(cam); r.set_constants(gs)
+            full, _ = r.render()
+            r.set_partition(1, 3)
+            packed = torch.zeros((r.tiles_count(1) * 1024, 4), dtype=torch.float32, device="cuda")
+            r.render_tiles(packed.data_ptr())
+            torch.cuda.synchronize()
+            want = tiles.pack_range(full, 1, 1, 3)
+            assert np.array_equal(packed.cpu().numpy().reshape(want.shape).view(np.uint32), want.view(np.uint32))
+            r.set_partition(0, 1)
+            # lit by the lat-long environment map (texture table without objects)
+            tex, sd_env = host.demo_textures(0, 0.0, textured=False, environment_map=True, return_scene_data=True)
+            tex_empty = type(tex)(0)
+            tex_empty.images = tex.images
+            r.set_scene(spheres[:0], materials[:0], sd_env)
+            r.set_textures(tex_empty)
+            img, _ = r.render()
+            ref, _ = oracle.render(spheres[:0], materials[:0], sd_env, cam, gs, threads=4, textures=tex_empty)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+            # and back to a real scene
+            r.set_scene(spheres, materials, sd)
+            r.set_camera(cam); r.set_constants(gs)
+            rect = (60, 40, 64, 48)
+            a, _ = r.render(rect)
+            ref, _ = oracle.render(spheres, materials, sd, cam, gs, rect=rect, threads=8)
+            assert np.array_equal(a.view(np.uint32)[..., :3], ref.view(np.uint32)[..., :3])
+    finally:
+        r.close()

@@ -294,3 +294,19 @@ def test_oracle_reproduces_the_golden_crops(dxrs, host, oracle):
         assert np.isfinite(gold).all() and gold[..., :3].std() > 0.01, c["file"]  # a crop with content
     src, dst, params = golden_cases.tonemap_case(dxrs)
     assert np.array_equal(oracle.tonemap(np.load(os.path.join(gold_dir, src)), params), np.load(os.path.join(gold_dir, dst)))
+
+
+def test_empty_scene_is_the_environment(dxrs, host, oracle):
+    """A scene without spheres (a TLAS without instances) is legal: every ray misses and every pixel is the environment, exactly the
+    frame of a scene whose only sphere lies behind the camera; one primary ray per pixel is counted, whatever the sample count."""
+    s, m, sd = host.scene(dxrs.host.SCENE_SMALL, seed=0)
+    w, h = 64, 40
+    for spp, bounces in ((1, 8), (3, 2)):
+        gs = dxrs.types.graphics_settings(w, h, frame_index=2, bounces=bounces, spp=spp)
+        cam = host.camera(w, h, jitter_index=1)
+        img, st = oracle.render(s[:0], m[:0], sd, cam, gs, threads=2)
+        behind = s[:1].copy()
+        behind["cx"], behind["cy"], behind["cz"], behind["r"] = 0.0, 0.0, -1e4, 0.5
+        ref, st_ref = oracle.render(behind, m[:1], sd, cam, gs, threads=2)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and st.rays == st_ref.rays == w * h
+        assert np.all(img[..., 3] == 1.0) and np.isfinite(img).all() and img[..., :3].min() > 0.0
