@@ -26,6 +26,11 @@ def cases(dxrs, host):
                     gs=t.graphics_settings(3840, 2160, frame_index=0, bounces=8, spp=16), rect=(1888, 1016, 64, 48), textures=None))
     out.append(dict(file="c4_crop_1888_1016_64x48.npy", spheres=s2, materials=m2, sd=sd2, cam=host.camera(3840, 2160, jitter_index=0),
                     gs=t.graphics_settings(3840, 2160, frame_index=0, bounces=16, spp=64), rect=(1888, 1016, 64, 48), textures=None))
+    # config C5 (2^20 procedural spheres + the ground, seed 1, 1920x1080, 1 spp, 8 bounces): the scene whose BVH lives in global memory --
+    # device LBVH, 4-wide quantised walk, split schedule with ray replacement on the GPU side; the oracle walks its own median-split tree
+    s5, m5, sd5 = host.scene(dxrs.host.SCENE_PROCEDURAL, seed=1, count=1 << 20)
+    out.append(dict(file="c5_crop_1200_560_64x32.npy", spheres=s5, materials=m5, sd=sd5, cam=host.camera(1920, 1080, jitter_index=0),
+                    gs=t.graphics_settings(1920, 1080, frame_index=0, bounces=8, spp=1), rect=(1200, 560, 64, 32), textures=None))
     # rows N1 + a18: the demo scene after 3 s with its textured objects, lit by the lat-long environment map (yaw pi), 2 spp:
     # a crop over the Earth and the Moon
     s3 = host.scene_at_time(0, 3.0)
