@@ -77,6 +77,8 @@ struct Lane {
     hipEvent_t ev_poll[4] = {};       // queue-size read-backs of the last passes (spp > 1 lagged polling)
     uint32_t scene_n = 0;             // sphere count the private copy was allocated for
     bool scene_private = false;
+    uint64_t sph_gen = 0;         // the pt_update_spheres generation this lane's private scene holds (PtContext::sph_gen)
+    bool needs_refit = false;     // spheres were staged on this lane and its boxes / Morton-ordered copy have not been redone yet
     bool upload_pending = false;  // h_stage holds spheres that have not been copied to d_sph yet (pt_update_spheres of a small scene: pt_refit_accel's kernel reads them)
     const void* last_out = nullptr;   // output buffer of the lane's latest frame (render_common: repeated buffers inside the window)
     // object rotations (textured scenes): the lane's own copy, refreshed from PtContext::h_rot when its generation is behind
@@ -147,6 +149,8 @@ struct PtContext {
     uint32_t last_lane = 0;
     hipEvent_t ev_in[kMaxLanes] = {};  // markers on `stream` at the start of the last n_lanes render calls
     uint64_t calls = 0;
+    uint64_t sph_gen = 0;      // counts pt_update_spheres calls since pt_set_scene; latest_lane: the lane whose staging buffer holds the newest spheres
+    int latest_lane = -1;
     bool empty_scene = false;  // pt_set_scene(n = 0): one internal sphere that no ray can hit stands in (see pt_set_scene)
     float4* d_out = nullptr;
     size_t cap_out = 0;
@@ -283,6 +287,7 @@ void free_lane_scene(Lane& L)
     L.scene_n = 0;
     L.scene_private = false;
     L.upload_pending = false;
+    L.needs_refit = false;
 }
 
 void free_lane_buffers(Lane& L)
@@ -564,15 +569,68 @@ PtStatus beam_cache_lookup(PtContext* c, const PixelMap& pm, const uint32_t** li
     return PT_OK;  // this frame still traverses; the next ones of this view find the lists
 }
 
-// pt_update_spheres of a small scene leaves the new spheres in the lane's pinned staging buffer for pt_refit_accel's kernel to read;
-// when no refit follows, the render call uploads them as before.
-static hipError_t flush_pending_upload(PtContext* c, Lane& L)
+// Moving spheres (row N2).  Every lane owns a copy of what moves (spheres, Morton-ordered spheres, node boxes) and a pinned staging
+// buffer.  stage_spheres_on_lane puts new spheres into L's staging buffer and gets them onto the device -- for small scenes by leaving
+// them there for refit_lane's single kernel (upload_pending), else with a copy on the lane's stream; refit_lane recomputes L's boxes.
+static PtStatus stage_spheres_on_lane(PtContext* c, Lane& L, const PtSphere* spheres)
 {
-    if (!L.upload_pending) return hipSuccess;
-    L.upload_pending = false;
-    hipError_t e = hipMemcpyAsync(L.d_sph, L.h_stage, (size_t)c->n * sizeof(float4), hipMemcpyHostToDevice, L.stream);
-    if (e == hipSuccess) e = hipEventRecord(L.ev_upload, L.stream);
-    return e;
+    const uint32_t n = c->n;
+    if (L.scene_n != n) {
+        PT_HIP(c, hipStreamSynchronize(L.stream));
+        free_lane_scene(L);
+        PT_HIP(c, hipMalloc(&L.d_sph, (size_t)n * sizeof(float4)));
+        PT_HIP(c, hipMalloc(&L.d_sph_sorted, (size_t)n * sizeof(float4)));
+        PT_HIP(c, hipMalloc(&L.d_nodes, (size_t)std::max(1u, n - 1) * sizeof(PtBvhNode)));
+        PT_HIP(c, hipMalloc(&L.d_refit_flags, (size_t)n * sizeof(uint32_t)));
+        PT_HIP(c, hipMalloc(&L.d_refit_hdr, 16 * sizeof(uint32_t)));
+        PT_HIP(c, hipHostMalloc(&L.h_stage, (size_t)n * sizeof(PtSphere)));
+        if (!L.ev_upload) PT_HIP(c, hipEventCreateWithFlags(&L.ev_upload, hipEventDisableTiming));
+        L.scene_n = n;
+    }
+    if (!L.scene_private) {
+        // first update on this lane: start from the master tree (topology + boxes), ordered after its build
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->n_nodes) PT_HIP(c, hipMemcpyAsync(L.d_nodes, c->d_nodes, (size_t)c->n_nodes * sizeof(PtBvhNode), hipMemcpyDeviceToDevice, L.stream));
+        L.scene_private = true;
+    } else {
+        PT_HIP(c, hipEventSynchronize(L.ev_upload));  // the previous upload from the staging buffer has been consumed
+    }
+    std::memcpy(L.h_stage, spheres, (size_t)n * sizeof(PtSphere));
+    L.needs_refit = true;
+    // Small scenes: no copy here -- refit_lane's single kernel reads the staging buffer (pinned host memory) itself, so a frame of
+    // an animated scene starts with ONE launch instead of a copy and four launches (DESIGN row N2).
+    if (lbvh_gpu_refit_fused_possible(n) && knob_or(c->knobs.fused_refit, 1u) != 0) { L.upload_pending = true; return PT_OK; }
+    PT_HIP(c, hipMemcpyAsync(L.d_sph, L.h_stage, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, L.stream));
+    PT_HIP(c, hipEventRecord(L.ev_upload, L.stream));
+    return PT_OK;
+}
+
+static PtStatus refit_lane(PtContext* c, Lane& L)
+{
+    L.needs_refit = false;
+    if (L.upload_pending) {
+        L.upload_pending = false;
+        PT_HIP(c, lbvh_gpu_refit_fused(c->gpu_builder, reinterpret_cast<const float4*>(L.h_stage), L.d_sph, c->n, reinterpret_cast<PtBvhNode*>(L.d_nodes), L.d_sph_sorted,
+                                       c->d_sorted_id, L.d_refit_hdr, L.stream));
+        PT_HIP(c, hipEventRecord(L.ev_upload, L.stream));  // the staging buffer has been read once this kernel is done
+        return PT_OK;
+    }
+    PT_HIP(c, lbvh_gpu_refit(c->gpu_builder, L.d_sph, c->n, reinterpret_cast<PtBvhNode*>(L.d_nodes), L.d_sph_sorted, c->d_sorted_id,
+                             L.d_refit_flags, L.d_refit_hdr, c->depth, L.stream));
+    return PT_OK;
+}
+
+// pt_update_spheres reaches the lane of the NEXT frame only; the frames after it run on other lanes, and they must see the moved spheres
+// too (an application that moves its spheres once and then renders on -- found by tests/test_gpu_stateful.py: two of three frames showed
+// the old positions).  A lane that is behind takes the newest spheres over from the staging buffer of the lane that received them and
+// refits its own boxes, on its own stream, before it renders.  An animated scene updates before every frame and never comes here.
+static PtStatus sync_lane_spheres(PtContext* c, Lane& L)
+{
+    if (c->latest_lane < 0 || L.sph_gen == c->sph_gen) return PT_OK;
+    const Lane& src = c->lanes[c->latest_lane];
+    if (PtStatus st = stage_spheres_on_lane(c, L, reinterpret_cast<const PtSphere*>(src.h_stage)); st != PT_OK) return st;
+    L.sph_gen = c->sph_gen;
+    return refit_lane(c, L);
 }
 
 // The per-frame launch sequence.  out: device float4 buffer addressed by PixelRef::out_index.
@@ -632,7 +690,8 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     PtStatus st = ensure_buffers(c, L, split ? pm.n_slots : std::max<size_t>(pm.n_slots, seg_total), spp > 1, split, wf_cap + 2, di);
     if (st != PT_OK) return st;
     if ((st = sync_lane_rotations(c, L)) != PT_OK) return st;
-    PT_HIP(c, flush_pending_upload(c, L));  // pt_update_spheres without pt_refit_accel: the spheres still reach the device
+    if ((st = sync_lane_spheres(c, L)) != PT_OK) return st;
+    if (L.needs_refit && (st = refit_lane(c, L)) != PT_OK) return st;  // pt_update_spheres without pt_refit_accel: the frame refits by itself
     c->last_lane = c->next_lane;
     c->next_lane = (c->next_lane + 1) % c->n_lanes;
     // Primary beams: use the cached candidate lists when this frame's view is the one they were built for; start a build
@@ -1060,7 +1119,9 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
     c->accel_valid = false;
     c->scene_gen++;
     free_textures(c);  // texture maps are per sphere: a new scene starts untextured
-    for (auto& L : c->lanes) { L.scene_private = false; L.upload_pending = false; }  // every lane renders the new master scene
+    for (auto& L : c->lanes) { L.scene_private = false; L.upload_pending = false; L.needs_refit = false; L.sph_gen = 0; }  // every lane renders the new master scene
+    c->sph_gen = 0;
+    c->latest_lane = -1;
     return PT_OK;
 }
 
@@ -1164,34 +1225,11 @@ PtStatus pt_update_spheres(PtContext* c, const PtSphere* spheres, uint32_t n)
             return fail(c, PT_ERR_INVALID_ARG, "pt_update_spheres: sphere " + std::to_string(i) + " has a non-finite centre or non-positive radius");
     PT_HIP(c, hipSetDevice(c->device));
     Lane& L = c->lanes[c->next_lane];  // the lane the next render call will use
-    if (L.scene_n != n) {
-        PT_HIP(c, hipStreamSynchronize(L.stream));
-        free_lane_scene(L);
-        PT_HIP(c, hipMalloc(&L.d_sph, (size_t)n * sizeof(float4)));
-        PT_HIP(c, hipMalloc(&L.d_sph_sorted, (size_t)n * sizeof(float4)));
-        PT_HIP(c, hipMalloc(&L.d_nodes, (size_t)std::max(1u, n - 1) * sizeof(PtBvhNode)));
-        PT_HIP(c, hipMalloc(&L.d_refit_flags, (size_t)n * sizeof(uint32_t)));
-        PT_HIP(c, hipMalloc(&L.d_refit_hdr, 16 * sizeof(uint32_t)));
-        PT_HIP(c, hipHostMalloc(&L.h_stage, (size_t)n * sizeof(PtSphere)));
-        if (!L.ev_upload) PT_HIP(c, hipEventCreateWithFlags(&L.ev_upload, hipEventDisableTiming));
-        L.scene_n = n;
-    }
-    if (!L.scene_private) {
-        // first update on this lane: start from the master tree (topology + boxes), ordered after its build
-        PT_HIP(c, hipStreamSynchronize(c->stream));
-        if (c->n_nodes) PT_HIP(c, hipMemcpyAsync(L.d_nodes, c->d_nodes, (size_t)c->n_nodes * sizeof(PtBvhNode), hipMemcpyDeviceToDevice, L.stream));
-        L.scene_private = true;
-    } else {
-        PT_HIP(c, hipEventSynchronize(L.ev_upload));  // the previous upload from the staging buffer has been consumed
-    }
     c->scene_gen++;
-    std::memcpy(L.h_stage, spheres, (size_t)n * sizeof(PtSphere));
-    // Small scenes: no copy here -- pt_refit_accel's single kernel reads the staging buffer (pinned host memory) itself, so a frame of
-    // an animated scene starts with ONE launch instead of a copy and four launches (DESIGN row N2).  A render call without a refit in
-    // between still uploads (flush_pending_upload).
-    if (lbvh_gpu_refit_fused_possible(n) && knob_or(c->knobs.fused_refit, 1u) != 0) { L.upload_pending = true; return PT_OK; }
-    PT_HIP(c, hipMemcpyAsync(L.d_sph, L.h_stage, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, L.stream));
-    PT_HIP(c, hipEventRecord(L.ev_upload, L.stream));
+    if (PtStatus st = stage_spheres_on_lane(c, L, spheres); st != PT_OK) return st;
+    // the other lanes take these spheres over from this lane's staging buffer when they render next (sync_lane_spheres)
+    L.sph_gen = ++c->sph_gen;
+    c->latest_lane = (int)c->next_lane;
     return PT_OK;
 }
 
@@ -1204,16 +1242,7 @@ PtStatus pt_refit_accel(PtContext* c)
     if (!c->accel_valid || !L.scene_private) return fail(c, PT_ERR_STATE, "pt_refit_accel: call pt_update_spheres first");
     const RoctxRange range(c, "pt_refit_accel");
     PT_HIP(c, hipSetDevice(c->device));
-    if (L.upload_pending) {
-        L.upload_pending = false;
-        PT_HIP(c, lbvh_gpu_refit_fused(c->gpu_builder, reinterpret_cast<const float4*>(L.h_stage), L.d_sph, c->n, reinterpret_cast<PtBvhNode*>(L.d_nodes), L.d_sph_sorted,
-                                       c->d_sorted_id, L.d_refit_hdr, L.stream));
-        PT_HIP(c, hipEventRecord(L.ev_upload, L.stream));  // the staging buffer has been read once this kernel is done
-        return PT_OK;
-    }
-    PT_HIP(c, lbvh_gpu_refit(c->gpu_builder, L.d_sph, c->n, reinterpret_cast<PtBvhNode*>(L.d_nodes), L.d_sph_sorted, c->d_sorted_id,
-                             L.d_refit_flags, L.d_refit_hdr, c->depth, L.stream));
-    return PT_OK;
+    return refit_lane(c, L);
 }
 
 PtStatus pt_set_camera(PtContext* c, const PtCamera* camera)

@@ -69,7 +69,11 @@ enum {
                                           consecutive render calls rotate over N internal streams ("lanes", each with its own
                                           work buffers) so that the latency-bound tail of one frame overlaps the start of the
                                           next ones.  The caller must rotate over N output buffers; whatever it queues on
-                                          `stream` after a render call is ordered after that frame. */
+                                          `stream` after a render call is ordered after that frame.  A frame itself is ordered
+                                          after what the caller had queued on `stream` before the render call N - 1 calls
+                                          earlier (the consumer of its buffer) -- NOT after work queued since then: do not
+                                          clear or fill an output buffer on `stream` right before rendering into it (every
+                                          pixel and every padding pixel is written by the frame anyway). */
 };
 
 typedef struct PtAccelInfo {
@@ -125,8 +129,10 @@ PtStatus pt_build_accel(PtContext *ctx, PtAccelInfo *info);
 /* Moving spheres (the reference rebuilds its TLAS every frame while the physics runs, Source/App.cpp:605-608):
  * pt_update_spheres uploads new centres / radii for the SAME n objects, pt_refit_accel recomputes every box of the
  * existing tree bottom-up (the topology of the last pt_build_accel is kept; any valid BVH gives identical images, only
- * traversal cost drifts -- call pt_set_scene + pt_build_accel again to rebuild).  Both are asynchronous and apply to the
- * frame of the NEXT render call (with two frames in flight: to that frame's lane), so call them before every frame. */
+ * traversal cost drifts -- call pt_set_scene + pt_build_accel again to rebuild).  Both are asynchronous.  The moved spheres hold for
+ * every frame from the next render call on, until they are moved again: the lane of the next frame receives them here, the other lanes
+ * take them over (and refit) when they render next.  pt_refit_accel may be omitted -- a render call whose lane has not been refitted since
+ * the spheres moved refits by itself; calling it lets the refit start before the render call is made. */
 PtStatus pt_update_spheres(PtContext *ctx, const PtSphere *spheres, uint32_t n);
 PtStatus pt_refit_accel(PtContext *ctx);
 PtStatus pt_set_camera(PtContext *ctx, const PtCamera *camera);

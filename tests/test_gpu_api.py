@@ -390,7 +390,7 @@ def test_empty_scene(dxrs, host, oracle):
             r.set_camera(cam); r.set_constants(gs)
             full, _ = r.render()
             r.set_partition(1, 3)
-            packed = torch.zeros((r.tiles_count(1) * 1024, 4), dtype=torch.float32, device="cuda")
+            packed = torch.empty((r.tiles_count(1) * 1024, 4), dtype=torch.float32, device="cuda")  # (no fill: see PT_FLAG_TWO_FRAMES_IN_FLIGHT)
             r.render_tiles(packed.data_ptr())
             torch.cuda.synchronize()
             want = tiles.pack_range(full, 1, 1, 3)

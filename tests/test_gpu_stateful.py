@@ -1,0 +1,174 @@
+"""Stateful fuzzing of the C-ABI: ONE context with three frames in flight lives through a random sequence of state changes -- new
+scenes (incl. empty and single-sphere ones and ones whose BVH lives in global memory), moved spheres with and without a refit,
+texture tables set / replaced / dropped, object rotations, partitions, rectangles, sample counts, direct illumination, resting and
+moving views (primary-beam lists built, used, invalidated) -- and EVERY frame it renders is compared with the CPU oracle bit for bit,
+ray count included.  The single-shot parity tests start from a fresh state each time; this one is after what survives between calls
+(per-lane scene copies, generation counters, pending uploads, cached lists): the kind of bug the round's rotation-generation defect was."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_fuzz import random_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _texture_set(dxrs, rng, n, with_env):
+    from dxrs_amd import abi_types as A
+    from dxrs_amd import textures as T
+    ts = T.TextureSet(n)
+    imgs = [ts.add_image(T.checker(32, 16, cells=4), srgb=True),
+            ts.add_image(T.planet_albedo(64, 32, seed=int(rng.integers(0, 100))), srgb=True),
+            ts.add_image(T.normal_map_from_height(T.value_noise(32, 32, seed=int(rng.integers(0, 100)))), srgb=False)]
+    for i in range(n):
+        if rng.random() < 0.5:
+            ts.assign(i, A.TEXTURE_MAP_BASE_COLOR, imgs[int(rng.integers(0, 2))])
+        if rng.random() < 0.3:
+            ts.assign(i, A.TEXTURE_MAP_NORMAL, imgs[2])
+        if rng.random() < 0.5:
+            ts.set_rotation(i, T.quaternion_axis_angle(rng.normal(size=3), float(rng.uniform(0, 6.28))))
+    env = None
+    if with_env:
+        env = ts.add_hdr_image(T.sky_latlong(64, 32, seed=int(rng.integers(0, 100))))
+    return ts, env
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_STATE_SEEDS", "6"))))
+def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
+    import torch
+    from dxrs_amd import tiles
+    rng = np.random.default_rng(7000 + seed)
+    sd0 = host.scene(dxrs.host.SCENE_SMALL)[2]
+    tstream = torch.cuda.Stream()
+    r = dxrs.Renderer(stream=tstream.cuda_stream, frames_in_flight=3)
+    state = dict(spheres=None, materials=None, sd=None, tex=None, w=64, h=48, spp=1, bounces=4, di=False, cam_seed=0, pos=(0.0, 0.5, -12.0), frame=0)
+    checked = 0
+    log = []
+
+    def new_scene():
+        n = int(rng.choice([0, 1, 2, 5, 40, 300, 5000]))
+        if n == 0:
+            s, m = random_scene(dxrs, rng, 1)
+            s, m = s[:0], m[:0]
+        else:
+            s, m = random_scene(dxrs, rng, n)
+        sd = copy.copy(sd0)
+        state.update(spheres=s, materials=m, sd=sd, tex=None)
+        log.append(f"scene n={len(s)}")
+        r.set_scene(s, m, sd)
+
+    def new_textures():
+        n = len(state["spheres"])
+        if rng.random() < 0.25:
+            log.append("drop textures")
+            state["tex"] = None
+            sd = copy.copy(sd0)
+            state["sd"] = sd
+            r.set_scene(state["spheres"], state["materials"], sd)  # (a fresh pt_set_scene is how a table is dropped)
+            return
+        ts, env = _texture_set(dxrs, rng, n, with_env=rng.random() < 0.5)
+        sd = copy.copy(sd0)
+        if env is not None:
+            sd.EnvironmentLightTextureDescriptor, sd.IsEnvironmentLightTextureCubeMap = env, 0
+        state.update(tex=ts, sd=sd)
+        log.append(f"textures env={env}")
+        r.set_scene(state["spheres"], state["materials"], sd)
+        r.set_textures(ts)
+
+    def move(refit):
+        s = state["spheres"].copy()
+        state["prev"] = state["spheres"]
+        if len(s) and refit:
+            k = rng.random(len(s)) < 0.7
+            s["cx"][k] += rng.uniform(-0.4, 0.4, int(k.sum())).astype(np.float32)
+            s["cy"][k] += rng.uniform(-0.4, 0.4, int(k.sum())).astype(np.float32)
+            s["r"][k] *= rng.uniform(0.8, 1.25, int(k.sum())).astype(np.float32)
+        state["spheres"] = s
+        log.append(f"move refit={refit}")
+        r.update_spheres(s, refit=refit)  # without a refit the spheres are the old ones: the old boxes stay valid
+
+    def rotate():
+        if state["tex"] is None or len(state["spheres"]) == 0:
+            return
+        from dxrs_amd import textures as T
+        for i in range(len(state["spheres"])):
+            if rng.random() < 0.5:
+                state["tex"].set_rotation(i, T.quaternion_axis_angle(rng.normal(size=3), float(rng.uniform(0, 6.28))))
+        log.append("rotate")
+        r.update_rotations(state["tex"].rotations)
+
+    def render():
+        nonlocal checked
+        w, h = state["w"], state["h"]
+        gs = dxrs.types.graphics_settings(w, h, frame_index=state["frame"], bounces=state["bounces"], spp=state["spp"], di=state["di"])
+        cam = host.camera(w, h, position=state["pos"], look_at=(0.0, 0.0, 0.0), jitter_index=state["cam_seed"])
+        state["frame"] += 1
+        r.set_camera(cam); r.set_constants(gs)
+        mode = rng.integers(0, 4)
+        ref_full = None
+        log.append(f"render mode={mode} {w}x{h} spp={state['spp']} b={state['bounces']} di={state['di']} tex={state['tex'] is not None} n={len(state['spheres'])}")
+
+        def oracle_frame(rect=None):
+            return oracle.render(state["spheres"], state["materials"], state["sd"], cam, gs, rect=rect, threads=8, textures=state["tex"])
+        if mode == 0 and w >= 48 and h >= 40:   # a rectangle
+            rect = (int(rng.integers(0, w - 40)), int(rng.integers(0, h - 32)), 40, 32)
+            img, st = r.render(rect)
+            ref, ost = oracle_frame(rect)
+            assert st.rays == ost.rays and np.array_equal(img.view(np.uint32)[..., :3], ref.view(np.uint32)[..., :3]), f"step {checked}: rect; " + " | ".join(log[-12:])
+        elif mode == 1:                          # this rank's tiles of a 3-rank job
+            rank = int(rng.integers(0, 3))
+            r.set_partition(rank, 3)
+            # (torch.empty, not zeros: a fill queued on the caller's stream right before the call is not something a frame on another
+            # lane waits for -- frames are ordered after the caller-stream work of frames_in_flight - 1 calls ago, include/pt_api.h)
+            packed = torch.empty((max(r.tiles_count(rank), 1) * 1024, 4), dtype=torch.float32, device="cuda")
+            r.render_tiles(packed.data_ptr())
+            torch.cuda.synchronize()
+            ref_full, _ = oracle_frame()
+            want = tiles.pack_range(ref_full, rank, 1, 3)
+            got = packed.cpu().numpy()[: want.shape[0] * 1024].reshape(want.shape)
+            if not np.array_equal(got.view(np.uint32)[..., :3], want.view(np.uint32)[..., :3]):
+                bad = int((got.view(np.uint32)[..., :3] != want.view(np.uint32)[..., :3]).any(-1).sum())
+                stale = None
+                if state.get("prev") is not None and len(state["prev"]) == len(state["spheres"]):
+                    old, _ = oracle.render(state["prev"], state["materials"], state["sd"], cam, gs, threads=8, textures=state["tex"])
+                    stale = bool(np.array_equal(got.view(np.uint32)[..., :3], tiles.pack_range(old, rank, 1, 3).view(np.uint32)[..., :3]))
+                raise AssertionError(f"step {checked}: tiles of rank {rank}: {bad} of {got.shape[0] * 1024} pixels differ; equals the frame of the spheres before the last move: {stale}; " + " | ".join(log[-12:]))
+            r.set_partition(0, 1)
+        else:                                    # whole frames, several in flight
+            n = int(rng.integers(1, 4))
+            bufs = [torch.empty((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(n)]
+            for b in bufs:
+                r.render_device(b.data_ptr())
+            torch.cuda.synchronize()
+            ref, _ = oracle_frame()
+            for b in bufs:  # the same frame n times: the later ones may go through the primary-beam lists
+                assert np.array_equal(b.cpu().numpy().view(np.uint32)[..., :3], ref.view(np.uint32)[..., :3]), f"step {checked}: frame; " + " | ".join(log[-12:])
+        checked += 1
+
+    try:
+        with torch.cuda.stream(tstream):
+            new_scene()
+            for step in range(28):
+                op = rng.integers(0, 10)
+                if op == 0:
+                    new_scene()
+                elif op == 1:
+                    new_textures()
+                elif op == 2:
+                    move(refit=True)
+                elif op == 3:
+                    move(refit=False)
+                elif op == 4:
+                    rotate()
+                elif op == 5:
+                    state.update(w=int(rng.choice([48, 64, 81, 160])), h=int(rng.choice([40, 48, 57, 96])))
+                elif op == 6:
+                    state.update(spp=int(rng.choice([1, 1, 2, 3])), bounces=int(rng.choice([0, 1, 4, 7])), di=bool(rng.random() < 0.4))
+                elif op == 7:
+                    state.update(pos=(float(rng.uniform(-2, 2)), float(rng.uniform(0, 2)), float(rng.uniform(-14, -9))), cam_seed=int(rng.integers(0, 64)))
+                render()
+    finally:
+        r.close()
+    assert checked == 28

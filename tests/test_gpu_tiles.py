@@ -188,6 +188,7 @@ def test_everything_together_tiles_textures_di_in_flight(dxrs, host, oracle):
     tex = [host.demo_textures(0, 0.5 * k) for k in range(n_frames)]
     gss = [t.graphics_settings(w, h, frame_index=k, bounces=4, spp=2, di=True) for k in range(n_frames)]
     cams = [host.camera(w, h, jitter_index=k) for k in range(n_frames)]
+    torch.cuda.synchronize()  # the fills above are done before any frame (a frame on another lane does not wait for work queued just before it)
     for k in range(n_frames):
         for rank, r in enumerate(rs):
             r.update_rotations(tex[k].rotations)
