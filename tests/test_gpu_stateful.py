@@ -42,7 +42,8 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
     rng = np.random.default_rng(7000 + seed)
     sd0 = host.scene(dxrs.host.SCENE_SMALL)[2]
     tstream = torch.cuda.Stream()
-    r = dxrs.Renderer(stream=tstream.cuda_stream, frames_in_flight=3)
+    lanes = (3, 1, 2)[seed % 3]
+    r = dxrs.Renderer(stream=tstream.cuda_stream, frames_in_flight=lanes)
     state = dict(spheres=None, materials=None, sd=None, tex=None, w=64, h=48, spp=1, bounces=4, di=False, cam_seed=0, pos=(0.0, 0.5, -12.0), frame=0)
     checked = 0
     log = []
@@ -137,7 +138,7 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
                 raise AssertionError(f"step {checked}: tiles of rank {rank}: {bad} of {got.shape[0] * 1024} pixels differ; equals the frame of the spheres before the last move: {stale}; " + " | ".join(log[-12:]))
             r.set_partition(0, 1)
         else:                                    # whole frames, several in flight
-            n = int(rng.integers(1, 4))
+            n = int(rng.integers(1, lanes + 1))
             bufs = [torch.empty((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(n)]
             for b in bufs:
                 r.render_device(b.data_ptr())
@@ -166,6 +167,11 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
                     state.update(w=int(rng.choice([48, 64, 81, 160])), h=int(rng.choice([40, 48, 57, 96])))
                 elif op == 6:
                     state.update(spp=int(rng.choice([1, 1, 2, 3])), bounces=int(rng.choice([0, 1, 4, 7])), di=bool(rng.random() < 0.4))
+                elif op == 8 and len(state["spheres"]):
+                    log.append("rebuild")
+                    r.set_scene(state["spheres"], state["materials"], state["sd"])  # the moved spheres become the master scene, new topology
+                    if state["tex"] is not None:
+                        r.set_textures(state["tex"])
                 elif op == 7:
                     state.update(pos=(float(rng.uniform(-2, 2)), float(rng.uniform(0, 2)), float(rng.uniform(-14, -9))), cam_seed=int(rng.integers(0, 64)))
                 render()
