@@ -47,6 +47,12 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
     state = dict(spheres=None, materials=None, sd=None, tex=None, w=64, h=48, spp=1, bounces=4, di=False, cam_seed=0, pos=(0.0, 0.5, -12.0), frame=0)
     checked = 0
     log = []
+    expected = dict(rays=0)  # what the device-accumulated ray total must read (checked and reset around every tile frame and at the end)
+
+    def check_totals():
+        tot = r.totals(reset=True)
+        assert tot.rays == expected["rays"], f"device ray total {tot.rays} != {expected['rays']} summed over the oracle's frames; " + " | ".join(log[-12:])
+        expected["rays"] = 0
 
     def new_scene():
         n = int(rng.choice([0, 1, 2, 5, 40, 300, 5000]))
@@ -118,8 +124,10 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
             img, st = r.render(rect)
             ref, ost = oracle_frame(rect)
             assert st.rays == ost.rays and np.array_equal(img.view(np.uint32)[..., :3], ref.view(np.uint32)[..., :3]), f"step {checked}: rect; " + " | ".join(log[-12:])
+            expected["rays"] += ost.rays
         elif mode == 1:                          # this rank's tiles of a 3-rank job
             rank = int(rng.integers(0, 3))
+            check_totals()
             r.set_partition(rank, 3)
             # (torch.empty, not zeros: a fill queued on the caller's stream right before the call is not something a frame on another
             # lane waits for -- frames are ordered after the caller-stream work of frames_in_flight - 1 calls ago, include/pt_api.h)
@@ -137,13 +145,15 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
                     stale = bool(np.array_equal(got.view(np.uint32)[..., :3], tiles.pack_range(old, rank, 1, 3).view(np.uint32)[..., :3]))
                 raise AssertionError(f"step {checked}: tiles of rank {rank}: {bad} of {got.shape[0] * 1024} pixels differ; equals the frame of the spheres before the last move: {stale}; " + " | ".join(log[-12:]))
             r.set_partition(0, 1)
+            r.totals(reset=True)  # (the oracle has no per-tile ray count to compare with)
         else:                                    # whole frames, several in flight
             n = int(rng.integers(1, lanes + 1))
             bufs = [torch.empty((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(n)]
             for b in bufs:
                 r.render_device(b.data_ptr())
             torch.cuda.synchronize()
-            ref, _ = oracle_frame()
+            ref, ost = oracle_frame()
+            expected["rays"] += n * ost.rays
             for b in bufs:  # the same frame n times: the later ones may go through the primary-beam lists
                 assert np.array_equal(b.cpu().numpy().view(np.uint32)[..., :3], ref.view(np.uint32)[..., :3]), f"step {checked}: frame; " + " | ".join(log[-12:])
         checked += 1
@@ -151,6 +161,7 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
     try:
         with torch.cuda.stream(tstream):
             new_scene()
+            r.totals(reset=True)
             for step in range(28):
                 op = rng.integers(0, 10)
                 if op == 0:
@@ -175,6 +186,7 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
                 elif op == 7:
                     state.update(pos=(float(rng.uniform(-2, 2)), float(rng.uniform(0, 2)), float(rng.uniform(-14, -9))), cam_seed=int(rng.integers(0, 64)))
                 render()
+            check_totals()
     finally:
         r.close()
     assert checked == 28
