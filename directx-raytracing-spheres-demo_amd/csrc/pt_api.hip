@@ -1077,12 +1077,12 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
     PtMaterial blank_material{};
     blank_material.IOR = 1.0f;
     if (empty) { spheres = &nan_sphere; materials = &blank_material; n = 1; }
-    c->empty_scene = empty;
     for (uint32_t i = 0; i < n && !empty; i++)
         if (!(spheres[i].r > 0.0f) || !std::isfinite(spheres[i].r) || !std::isfinite(spheres[i].cx) || !std::isfinite(spheres[i].cy) || !std::isfinite(spheres[i].cz))
             return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: sphere " + std::to_string(i) + " has a non-finite centre or non-positive radius");
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, sync_all(c));  // frames in flight still read the old scene
+    c->empty_scene = empty;  // (after every check that can reject the call)
     if (n != c->n) {
         free_dev(c->d_sph); free_dev(c->d_mats);
         PT_HIP(c, hipMalloc(&c->d_sph, (size_t)n * sizeof(float4)));
@@ -1427,12 +1427,14 @@ PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_tex
     if (!c) return PT_ERR_INVALID_ARG;
     if (!c->scene_set) return fail(c, PT_ERR_STATE, "pt_set_textures: call pt_set_scene first");
     PT_HIP(c, hipSetDevice(c->device));
-    PT_HIP(c, sync_all(c));
-    free_textures(c);
-    if (n_textures == 0) return PT_OK;
+    if (n_textures == 0) {  // drops the table
+        PT_HIP(c, sync_all(c));
+        free_textures(c);
+        return PT_OK;
+    }
     if (!textures) return fail(c, PT_ERR_INVALID_ARG, "pt_set_textures: null pointer");
     const uint32_t n = c->n;
-    // validate before touching the device
+    // validate before touching the device or the table in use: a rejected call leaves the previous textures in place
     for (uint32_t t = 0; t < n_textures; t++) {
         const PtTexture& tx = textures[t];
         if (!tx.Pixels || tx.Width == 0 || tx.Height == 0 || tx.Width > 16384 || tx.Height > 16384 || tx.Format > PT_TEXTURE_RGBA32_FLOAT)
@@ -1453,6 +1455,8 @@ PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_tex
         }
         maps[(size_t)i * 8u + 7u] = any;
     }
+    PT_HIP(c, sync_all(c));  // frames in flight may still sample the old table
+    free_textures(c);
     // 8-bit texels -> linear float4 (the conversion D3D's sampler does per fetch, done once; sRGB through from_srgb)
     float unorm_lut[256], srgb_lut[256];
     for (int v = 0; v < 256; v++) { unorm_lut[v] = (float)v * (1.0f / 255.0f); srgb_lut[v] = pt::from_srgb(unorm_lut[v]); }

@@ -15,6 +15,21 @@ from test_gpu_fuzz import random_scene
 pytestmark = pytest.mark.gpu
 
 
+class _named:
+    """names the call in the failure when the C-ABI accepts what it should refuse"""
+
+    def __init__(self, what):
+        self.what = what
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is None:
+            raise AssertionError(self.what + ": accepted")
+        return False
+
+
 def _texture_set(dxrs, rng, n, with_env):
     from dxrs_amd import abi_types as A
     from dxrs_amd import textures as T
@@ -106,6 +121,36 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
         log.append("rotate")
         r.update_rotations(state["tex"].rotations)
 
+    def rejected_call():
+        """a call the C-ABI must refuse -- and must leave no trace of: the frames after it still match the oracle"""
+        from dxrs_amd import textures as T
+        kind = int(rng.integers(0, 6))
+        n = len(state["spheres"])
+        if kind == 3 and n == 0:
+            kind = 4  # (an empty scene has no object whose maps could name a texture)
+        log.append(f"rejected call {kind}")
+        with pytest.raises(dxrs.PtError), _named(f"rejected call {kind} with n = {n}, textured = {state['tex'] is not None}"):
+            if kind == 0:    # the sphere count must not change
+                bad = np.concatenate([state["spheres"], state["spheres"][:1]]) if n else random_scene(dxrs, rng, 1)[0]
+                r.update_spheres(bad)
+            elif kind == 1:  # a non-finite sphere
+                bad = state["spheres"].copy() if n else random_scene(dxrs, rng, 1)[0]
+                bad["cx"][0] = np.nan
+                (r.update_spheres if n else (lambda b: r.set_scene(b, random_scene(dxrs, rng, 1)[1], state["sd"])))(bad)
+            elif kind == 2:  # a rectangle outside the frame
+                gs = dxrs.types.graphics_settings(state["w"], state["h"], bounces=1, spp=1)
+                r.set_constants(gs); r.set_camera(host.camera(state["w"], state["h"]))
+                r.render((state["w"] - 8, 0, 16, 8))
+            elif kind == 3:  # a texture descriptor outside the table: the table in use must survive
+                ts = T.TextureSet(max(n, 1))
+                ts.add_image(T.checker(8, 8, cells=2), srgb=True)
+                ts.assign(0, 0, 7)
+                r.set_textures(ts)
+            elif kind == 4:  # a partition that is none
+                r.set_partition_ex(2, 2, 3)
+            else:            # rotations for a different number of objects (or for an untextured scene)
+                r.update_rotations(np.tile(np.array([0, 0, 0, 1], dtype=np.float32), (n + 2, 1)))
+
     def render():
         nonlocal checked
         w, h = state["w"], state["h"]
@@ -183,6 +228,8 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
                     r.set_scene(state["spheres"], state["materials"], state["sd"])  # the moved spheres become the master scene, new topology
                     if state["tex"] is not None:
                         r.set_textures(state["tex"])
+                elif op == 9:
+                    rejected_call()
                 elif op == 7:
                     state.update(pos=(float(rng.uniform(-2, 2)), float(rng.uniform(0, 2)), float(rng.uniform(-14, -9))), cam_seed=int(rng.integers(0, 64)))
                 render()
