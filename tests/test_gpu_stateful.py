@@ -58,7 +58,10 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
     sd0 = host.scene(dxrs.host.SCENE_SMALL)[2]
     tstream = torch.cuda.Stream()
     lanes = (3, 1, 2)[seed % 3]
-    r = dxrs.Renderer(stream=tstream.cuda_stream, frames_in_flight=lanes)
+    # the context-wide switches, too: fused / split schedule, SAH topology / device LBVH, BVH in LDS / in global memory
+    from dxrs_amd import abi_types as A
+    flags = (0, 0, A.PT_FLAG_SPLIT_KERNELS, A.PT_FLAG_FAST_BUILD, A.PT_FLAG_NO_LDS_SCENE, A.PT_FLAG_NO_LDS_SCENE | A.PT_FLAG_FAST_BUILD)[(seed // 3) % 6]
+    r = dxrs.Renderer(stream=tstream.cuda_stream, frames_in_flight=lanes, flags=flags)
     state = dict(spheres=None, materials=None, sd=None, tex=None, w=64, h=48, spp=1, bounces=4, di=False, cam_seed=0, pos=(0.0, 0.5, -12.0), frame=0)
     checked = 0
     log = []
