@@ -50,7 +50,7 @@ def _texture_set(dxrs, rng, n, with_env):
     return ts, env
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_STATE_SEEDS", "6"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_STATE_SEEDS", "18"))))
 def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
     import torch
     from dxrs_amd import tiles
