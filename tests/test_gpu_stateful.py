@@ -211,7 +211,7 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
             new_scene()
             r.totals(reset=True)
             for step in range(28):
-                op = rng.integers(0, 10)
+                op = rng.integers(0, 12)
                 if op == 0:
                     new_scene()
                 elif op == 1:
@@ -233,6 +233,16 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
                         r.set_textures(state["tex"])
                 elif op == 9:
                     rejected_call()
+                elif op == 10:  # per-launch event profiling on / off, read-outs in between: no influence on any frame
+                    on = bool(rng.random() < 0.5)
+                    log.append(f"profiling {on}")
+                    r.set_profiling(on)
+                    p = r.profile(reset=bool(rng.random() < 0.5))
+                    assert p.ms_traverse >= 0.0 and p.ms_tail >= 0.0
+                    r.queue_sizes()
+                elif op == 11:
+                    log.append("synchronize")
+                    r.synchronize()
                 elif op == 7:
                     state.update(pos=(float(rng.uniform(-2, 2)), float(rng.uniform(0, 2)), float(rng.uniform(-14, -9))), cam_seed=int(rng.integers(0, 64)))
                 render()
