@@ -250,3 +250,65 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
     finally:
         r.close()
     assert checked == 28
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_PIPE_SEEDS", "6"))))
+def test_pipelined_sequences_match_oracle(dxrs, host, oracle, seed):
+    """The same idea without a host synchronisation between frames: 14 frames go through the lanes back to back while the spheres move
+    (with an explicit refit, without one, or not at all), object rotations change, and the view rests (beam lists are built on the side
+    stream and picked up) or moves; the caller's stream snapshots every frame right after its render call.  Only then does the host wait,
+    and every snapshot must be the oracle's frame -- ordering between lanes, the side stream and the caller's stream is what is on trial."""
+    import torch
+    from dxrs_amd import textures as T
+    rng = np.random.default_rng(9000 + seed)
+    lanes = (3, 2, 3, 1)[seed % 4]
+    n = int(rng.choice([40, 441, 3000]))
+    spheres, materials = random_scene(dxrs, rng, n)
+    sd = copy.copy(host.scene(dxrs.host.SCENE_SMALL)[2])
+    textured = bool(seed % 2)
+    ts = None
+    if textured:
+        ts, env = _texture_set(dxrs, rng, n, with_env=bool(rng.random() < 0.5))
+        if env is not None:
+            sd.EnvironmentLightTextureDescriptor, sd.IsEnvironmentLightTextureCubeMap = env, 0
+    w, h = 320, 200
+    tstream = torch.cuda.Stream()
+    r = dxrs.Renderer(stream=tstream.cuda_stream, frames_in_flight=lanes)
+    try:
+        with torch.cuda.stream(tstream):
+            r.set_scene(spheres, materials, sd)
+            if ts is not None:
+                r.set_textures(ts)
+            bufs = [torch.empty((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(lanes)]
+            torch.cuda.synchronize()
+            pos, cam_seed = (0.0, 0.5, -12.0), 0
+            snaps, frames = [], []
+            for k in range(14):
+                what = int(rng.integers(0, 6))
+                if what == 0 or what == 1:
+                    s2 = spheres.copy()
+                    mv = rng.random(n) < 0.5
+                    s2["cy"][mv] += rng.uniform(-0.2, 0.2, int(mv.sum())).astype(np.float32)
+                    spheres = s2
+                    r.update_spheres(spheres, refit=(what == 0))
+                elif what == 2 and ts is not None:
+                    for i in range(n):
+                        if rng.random() < 0.3:
+                            ts.set_rotation(i, T.quaternion_axis_angle(rng.normal(size=3), float(rng.uniform(0, 6.28))))
+                    r.update_rotations(ts.rotations)
+                elif what == 3:
+                    pos, cam_seed = (float(rng.uniform(-1, 1)), float(rng.uniform(0, 1.5)), float(rng.uniform(-13, -10))), int(rng.integers(0, 64))
+                gs = dxrs.types.graphics_settings(w, h, frame_index=k, bounces=int(rng.choice([2, 5])), spp=int(rng.choice([1, 1, 2])), di=bool(rng.random() < 0.3))
+                cam = host.camera(w, h, position=pos, look_at=(0.0, 0.0, 0.0), jitter_index=cam_seed)
+                r.set_camera(cam); r.set_constants(gs)
+                r.render_device(bufs[k % lanes].data_ptr())
+                snaps.append(bufs[k % lanes].clone())  # on the caller's stream: after frame k, before the frame that reuses the buffer
+                frames.append((spheres, None if ts is None else copy.deepcopy(ts.rotations), cam, gs))
+            torch.cuda.synchronize()
+        for k, (sph, rot, cam, gs) in enumerate(frames):
+            if ts is not None:
+                ts.rotations[:] = rot
+            ref, _ = oracle.render(sph, materials, sd, cam, gs, threads=8, textures=ts)
+            assert np.array_equal(snaps[k].cpu().numpy().view(np.uint32)[..., :3], ref.view(np.uint32)[..., :3]), f"frame {k} of sequence {seed} ({lanes} lanes, {n} spheres)"
+    finally:
+        r.close()
