@@ -211,7 +211,7 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
             new_scene()
             r.totals(reset=True)
             for step in range(28):
-                op = rng.integers(0, 12)
+                op = rng.integers(0, 13)
                 if op == 0:
                     new_scene()
                 elif op == 1:
@@ -243,6 +243,9 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
                 elif op == 11:
                     log.append("synchronize")
                     r.synchronize()
+                elif op == 12:  # pt_build_accel alone rebuilds the tree of the spheres of the last pt_set_scene: no effect on what the lanes hold
+                    log.append("build_accel")
+                    r.build_accel()
                 elif op == 7:
                     state.update(pos=(float(rng.uniform(-2, 2)), float(rng.uniform(0, 2)), float(rng.uniform(-14, -9))), cam_seed=int(rng.integers(0, 64)))
                 render()
