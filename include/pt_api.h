@@ -210,7 +210,8 @@ PtStatus pt_accumulate(PtContext *ctx, void *accum_device, const void *radiance_
                        uint32_t frames_accumulated);
 
 /* Test / tooling hooks. */
-/* Closest hit of n rays against the current accel: o,d = n*3 floats (d unit length), tmin per call.
+/* Closest hit of n rays against the scene and accel of the last pt_set_scene / pt_build_accel (spheres moved by pt_update_spheres live in
+ * the lanes' private copies and are not seen here): o,d = n*3 floats (d unit length), tmin per call.
  * Outputs host arrays t[n], id[n] (id = 0xFFFFFFFF on miss).  use_bvh = 0 runs the device brute-force kernel. */
 PtStatus pt_trace_rays(PtContext *ctx, const float *origins, const float *directions, uint32_t n, float tmin,
                        int use_bvh, float *out_t, uint32_t *out_id);
