@@ -100,6 +100,29 @@ def test_ragged_and_tiny_frames(dxrs, host, oracle, renderer, w, h, rect):
     assert count_mismatch(img, ref) == 0
 
 
+@pytest.mark.parametrize("w,h", [(65535, 1), (1, 65535), (65535, 3), (2, 40000)])
+def test_maximum_extents(dxrs, host, oracle, renderer, w, h):
+    """The largest RenderSize the interface accepts in one dimension (65535: the RNG seed packs (x << 16) | y), as slivers the oracle finishes
+    in seconds: whole frames and, through the tile path, one rank's share of them."""
+    import torch
+    from dxrs_amd import tiles
+    scene = host.scene(dxrs.host.SCENE_SMALL, seed=0)
+    img, stats, ref, ostats = _render_both(dxrs, host, oracle, renderer, scene, w, h, 3, 1)
+    assert img.shape == ref.shape == (h, w, 4) and stats.rays == ostats.rays and stats.pixels == w * h
+    assert count_mismatch(img, ref) == 0
+    try:
+        renderer.set_partition(1, 3)
+        n_tiles = renderer.tiles_count(1)
+        packed = torch.empty((n_tiles * 1024, 4), dtype=torch.float32, device="cuda")
+        renderer.render_tiles(packed.data_ptr())
+        torch.cuda.synchronize()
+        want = tiles.pack_range(ref, 1, 1, 3)
+        assert want.shape[0] == n_tiles
+        assert np.array_equal(packed.cpu().numpy().reshape(want.shape).view(np.uint32)[..., :3], want.view(np.uint32)[..., :3])
+    finally:
+        renderer.set_partition(0, 1)
+
+
 def test_more_ranks_than_tiles(dxrs, host, renderer):
     """A rank that owns no tile renders nothing and reports zero work."""
     import torch
