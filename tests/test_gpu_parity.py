@@ -123,6 +123,16 @@ def test_maximum_extents(dxrs, host, oracle, renderer, w, h):
         renderer.set_partition(0, 1)
 
 
+@pytest.mark.parametrize("w,h,spp,bounces,rr", [(4, 3, 65535, 2, True), (32, 16, 1, 250, False), (8, 8, 300, 250, False)])
+def test_maximum_counts(dxrs, host, oracle, renderer, w, h, spp, bounces, rr):
+    """The largest SamplesPerPixel (65535) and Bounces (250) the interface accepts: the sample counter and the bounce counter of the ray
+    record at the ends of their ranges, the looping pass at its longest."""
+    scene = host.scene(dxrs.host.SCENE_SMALL, seed=0)
+    img, stats, ref, ostats = _render_both(dxrs, host, oracle, renderer, scene, w, h, bounces, spp, rr=rr)
+    assert stats.rays == ostats.rays
+    assert count_mismatch(img, ref) == 0
+
+
 def test_more_ranks_than_tiles(dxrs, host, renderer):
     """A rank that owns no tile renders nothing and reports zero work."""
     import torch
