@@ -133,6 +133,26 @@ def test_maximum_counts(dxrs, host, oracle, renderer, w, h, spp, bounces, rr):
     assert count_mismatch(img, ref) == 0
 
 
+@pytest.mark.parametrize("near,far", [(0.0, float("inf")), (0.0, 3.0e38), (5.0, 14.0), (20.0, 10.0)])
+@pytest.mark.parametrize("empty", [False, True])
+def test_depth_range_extremes(dxrs, host, oracle, renderer, near, far, empty):
+    """NearDepth / FarDepth bound the primary rays only (Camera.hlsli:27-41): no bound at all (0 .. inf -- also the case in which the
+    stand-in sphere of an empty scene must stay unhittable without the help of tmax), a slab that cuts the scene, and an empty range."""
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_SMALL, seed=0)
+    if empty:
+        spheres, materials = spheres[:0], materials[:0]
+    w, h = 96, 64
+    gs = dxrs.types.graphics_settings(w, h, frame_index=3, bounces=4, spp=2)
+    cam = host.camera(w, h, jitter_index=3)
+    cam.NearDepth, cam.FarDepth = near, far
+    renderer.set_scene(spheres, materials, sd)
+    renderer.set_camera(cam); renderer.set_constants(gs)
+    img, stats = render_rested(renderer, None)
+    ref, ostats = oracle.render(spheres, materials, sd, cam, gs, threads=8)
+    assert stats.rays == ostats.rays and np.isfinite(img).all()
+    assert count_mismatch(img, ref) == 0
+
+
 def test_more_ranks_than_tiles(dxrs, host, renderer):
     """A rank that owns no tile renders nothing and reports zero work."""
     import torch
