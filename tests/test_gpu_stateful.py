@@ -34,7 +34,8 @@ def _texture_set(dxrs, rng, n, with_env):
     from dxrs_amd import abi_types as A
     from dxrs_amd import textures as T
     ts = T.TextureSet(n)
-    imgs = [ts.add_image(T.checker(32, 16, cells=4), srgb=True),
+    odd = rng.integers(0, 3)  # sizes the samplers' wrap addressing has to cope with: 1 x 1, odd, wide
+    imgs = [ts.add_image(T.checker(*((1, 1, 1), (7, 5, 2), (32, 16, 4))[odd][:2], cells=((1, 1, 1), (7, 5, 2), (32, 16, 4))[odd][2]), srgb=True),
             ts.add_image(T.planet_albedo(64, 32, seed=int(rng.integers(0, 100))), srgb=True),
             ts.add_image(T.normal_map_from_height(T.value_noise(32, 32, seed=int(rng.integers(0, 100)))), srgb=False)]
     for i in range(n):
