@@ -78,6 +78,57 @@ def test_bvh_equals_brute_force(dxrs, host, oracle, name, count, flags):
         r.close()
 
 
+@pytest.mark.parametrize("kind", ["concentric", "line", "identical", "far_from_origin", "two_clusters"])
+@pytest.mark.parametrize("n", [2, 500, 6000])
+@pytest.mark.parametrize("flags", [0, 64, 1])  # default builder (SAH up to 4096 spheres) / PT_FLAG_FAST_BUILD (device LBVH) / PT_FLAG_NO_LDS_SCENE
+def test_degenerate_layouts_bvh_equals_brute_force(dxrs, host, kind, n, flags):
+    """Sphere layouts that degenerate the builders' inputs: one centre for all spheres (every Morton key equal, zero-extent centroid
+    bounds), centres on a line (two axes without extent), n copies of one sphere (every key and every box equal: ties by index), a cluster
+    far from the origin (padding and quantisation at large coordinates), two clusters a million units apart (nearly all Morton cells
+    empty).  Whatever tree comes out, the closest hit must be the brute-force one, bit for bit, ties to the lowest id."""
+    rng = np.random.default_rng(n * 31 + len(kind))
+    s = np.zeros(n, dtype=dxrs.SPHERE_DTYPE)
+    if kind == "concentric":
+        s["cx"], s["cy"], s["cz"] = 0.5, -0.25, 2.0
+        s["r"] = rng.uniform(0.1, 5.0, n)
+    elif kind == "line":
+        s["cx"] = rng.uniform(-50, 50, n); s["cy"], s["cz"] = 1.0, -3.0
+        s["r"] = rng.uniform(0.05, 0.6, n)
+    elif kind == "identical":
+        s["cx"], s["cy"], s["cz"], s["r"] = 1.0, 2.0, 3.0, 0.75
+    elif kind == "far_from_origin":
+        s["cx"] = 1.0e5 + rng.uniform(-3, 3, n); s["cy"] = -2.0e5 + rng.uniform(-3, 3, n); s["cz"] = 3.0e4 + rng.uniform(-3, 3, n)
+        s["r"] = rng.uniform(0.05, 0.5, n)
+    else:
+        half = n // 2
+        s["cx"][:half] = rng.uniform(-2, 2, half); s["cx"][half:] = 1.0e6 + rng.uniform(-2, 2, n - half)
+        s["cy"] = rng.uniform(-2, 2, n); s["cz"] = rng.uniform(-2, 2, n)
+        s["r"] = rng.uniform(0.05, 0.5, n)
+    m = dxrs.types.default_material(n)
+    sd = host.scene(dxrs.host.SCENE_SMALL)[2]
+    r = dxrs.Renderer(flags=flags)
+    try:
+        info = r.set_scene(s, m, sd)
+        assert info.leaf_count == n and info.node_count == n - 1
+        # rays from near a randomly picked sphere towards (a jittered point of) another one, half of them; random directions for the rest
+        nr = 40000
+        c = np.stack([s["cx"], s["cy"], s["cz"]], 1).astype(np.float64)
+        a_, b_ = rng.integers(0, n, nr), rng.integers(0, n, nr)
+        o = c[a_] + rng.normal(size=(nr, 3)) * 4.0
+        tgt = c[b_] + rng.normal(size=(nr, 3)) * s["r"][b_, None] * 0.7
+        d = np.where((np.arange(nr) % 2 == 0)[:, None], tgt - o, rng.normal(size=(nr, 3)))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        o, d = o.astype(np.float32), d.astype(np.float32)
+        d /= np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+        for tmin in (0.0, 0.3):
+            t_bvh, id_bvh = r.trace_rays(o, d, tmin=tmin, use_bvh=True)
+            t_bf, id_bf = r.trace_rays(o, d, tmin=tmin, use_bvh=False)
+            assert np.array_equal(id_bvh, id_bf) and np.array_equal(t_bvh.view(np.uint32), t_bf.view(np.uint32))
+            assert (id_bvh != 0xFFFFFFFF).mean() > 0.2
+    finally:
+        r.close()
+
+
 def candidates(spheres, o, d):
     """cheap float64 prefilter so the per-ray oracle loop only visits spheres the ray passes near (margin 1e-3 r)"""
     c = np.stack([spheres["cx"], spheres["cy"], spheres["cz"]], 1).astype(np.float64) - o.astype(np.float64)
