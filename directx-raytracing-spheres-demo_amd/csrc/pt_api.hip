@@ -123,6 +123,14 @@ struct PtContext {
     uint32_t* d_lights = nullptr;
     uint32_t n_lights = 0;
 
+    // alpha-tested hits (spec S10): the spheres whose AlphaMode is not Opaque, their class per sphere on the device (null while
+    // every sphere is kAlphaVisible) and the leaf ids carrying it (Morton order; null = the traversal reads d_sorted_id)
+    struct AlphaMat { uint32_t id; float base[4]; float cutoff; uint32_t base_map; };
+    std::vector<AlphaMat> alpha_mats;
+    uint32_t* d_alpha_class = nullptr;
+    uint32_t* d_leaf_ids = nullptr;
+    bool alpha_tested = false;
+
     // accel
     float4* d_nodes = nullptr;
     float4* d_wide = nullptr;        // 4-wide view of the tree (global-memory scenes only; null otherwise)
@@ -376,6 +384,43 @@ PtStatus sync_lane_rotations(PtContext* c, Lane& L)
     return PT_OK;
 }
 
+// Alpha-tested hits (pt_device.h): classify the non-opaque spheres from their materials and base-colour maps, and (when the tree
+// exists) rebuild the flagged leaf ids.  Called, with nothing in flight, whenever materials, maps or the tree change.
+PtStatus refresh_leaf_ids(PtContext* c)
+{
+    free_dev(c->d_leaf_ids);
+    if (!c->d_alpha_class || !c->accel_valid) return PT_OK;
+    PT_HIP(c, hipMalloc(&c->d_leaf_ids, (size_t)c->n * sizeof(uint32_t)));
+    PT_HIP(c, launch_leaf_ids(c->d_sorted_id, c->d_alpha_class, c->n, c->d_leaf_ids, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+PtStatus update_alpha_classes(PtContext* c)
+{
+    std::vector<uint32_t> cls;
+    bool any = false, tested = false;
+    for (const auto& am : c->alpha_mats) {
+        // EvaluateBaseColor samples the map when any component of the float4 BaseColor is positive (ShadingHelpers.hlsli:61-72)
+        const bool sampled = c->has_textures && am.base_map != ~0u && (am.base[0] > 0.0f || am.base[1] > 0.0f || am.base[2] > 0.0f || am.base[3] > 0.0f);
+        const uint32_t k = sampled ? kAlphaTested : (am.base[3] >= am.cutoff ? kAlphaVisible : kAlphaInvisible);
+        if (k != kAlphaVisible) {
+            if (cls.empty()) cls.assign(c->n, kAlphaVisible);
+            cls[am.id] = k;
+            any = true;
+            tested = tested || k == kAlphaTested;
+        }
+    }
+    free_dev(c->d_alpha_class);
+    c->alpha_tested = tested;
+    if (any) {
+        PT_HIP(c, hipMalloc(&c->d_alpha_class, (size_t)c->n * sizeof(uint32_t)));
+        PT_HIP(c, hipMemcpy(c->d_alpha_class, cls.data(), (size_t)c->n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    c->scene_gen++;  // what a ray can hit has changed (primary-beam lists)
+    return refresh_leaf_ids(c);
+}
+
 PtStatus validate_frame(PtContext* c)
 {
     if (!c->scene_set) return fail(c, PT_ERR_STATE, "pt_set_scene has not been called");
@@ -400,7 +445,9 @@ SceneView make_scene_view(const PtContext* c, const Lane* L = nullptr)
     sv.nodes = priv ? L->d_nodes : c->d_nodes;
     sv.wide = priv ? nullptr : c->d_wide;  // (a lane's refitted private tree is walked through its binary records)
     sv.sph_sorted = priv ? L->d_sph_sorted : c->d_sph_sorted;
-    sv.sorted_id = c->d_sorted_id;
+    sv.sorted_id = c->d_leaf_ids ? c->d_leaf_ids : c->d_sorted_id;
+    sv.alpha_class = c->d_alpha_class;
+    sv.alpha_tested = c->alpha_tested ? 1u : 0u;
     sv.sph = priv ? L->d_sph : c->d_sph;
     sv.mats = c->d_mats;
     sv.n = c->n;
@@ -1047,7 +1094,7 @@ void pt_destroy(PtContext* c)
         if (L.ev_done) (void)hipEventDestroy(L.ev_done);
         if (L.stream && L.stream != c->stream) (void)hipStreamDestroy(L.stream);
     }
-    free_dev(c->d_sph); free_dev(c->d_mats); free_dev(c->d_nodes); free_dev(c->d_wide); free_dev(c->d_sph_sorted); free_dev(c->d_sorted_id); free_dev(c->d_lights);
+    free_dev(c->d_sph); free_dev(c->d_mats); free_dev(c->d_nodes); free_dev(c->d_wide); free_dev(c->d_sph_sorted); free_dev(c->d_sorted_id); free_dev(c->d_lights); free_dev(c->d_alpha_class); free_dev(c->d_leaf_ids);
     free_dev(c->beam.d_lists);
     if (c->beam.ev_ready) (void)hipEventDestroy(c->beam.ev_ready);
     if (c->beam.ev_last_use) (void)hipEventDestroy(c->beam.ev_last_use);
@@ -1082,12 +1129,35 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
             return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: sphere " + std::to_string(i) + " has a non-finite centre or non-positive radius");
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, sync_all(c));  // frames in flight still read the old scene
-    c->empty_scene = empty;  // (after every check that can reject the call)
-    if (n != c->n) {
-        free_dev(c->d_sph); free_dev(c->d_mats);
-        PT_HIP(c, hipMalloc(&c->d_sph, (size_t)n * sizeof(float4)));
-        PT_HIP(c, hipMalloc(&c->d_mats, (size_t)n * sizeof(PtMaterial)));
+    // the emitters, in id order (LightPreparation::CountLights, Source/LightPreparation.ixx:52-70: objects with any emission > 0)
+    std::vector<uint32_t> lights;
+    for (uint32_t i = 0; i < n; i++) {
+        const PtMaterial& m = materials[i];
+        if (m.EmissiveStrength * m.EmissiveColor[0] > 0.0f || m.EmissiveStrength * m.EmissiveColor[1] > 0.0f || m.EmissiveStrength * m.EmissiveColor[2] > 0.0f)
+            lights.push_back(i);
     }
+    // Every allocation that can fail comes first, into temporaries: a call that runs out of memory leaves the previous scene intact
+    // (nothing of the context has been touched yet).
+    float4* new_sph = nullptr;
+    float4* new_mats = nullptr;
+    uint32_t* new_lights = nullptr;
+    if (n != c->n || !c->d_sph || !c->d_mats) {
+        if (hipMalloc(&new_sph, (size_t)n * sizeof(float4)) != hipSuccess || hipMalloc(&new_mats, (size_t)n * sizeof(PtMaterial)) != hipSuccess) {
+            (void)hipGetLastError();
+            free_dev(new_sph); free_dev(new_mats);
+            return fail(c, PT_ERR_OOM, "pt_set_scene: out of device memory (the previous scene is unchanged)");
+        }
+    }
+    if (!lights.empty() && hipMalloc(&new_lights, lights.size() * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        free_dev(new_sph); free_dev(new_mats);
+        return fail(c, PT_ERR_OOM, "pt_set_scene: out of device memory (the previous scene is unchanged)");
+    }
+    c->empty_scene = empty;  // (after every check that can reject the call)
+    if (new_sph) { free_dev(c->d_sph); free_dev(c->d_mats); c->d_sph = new_sph; c->d_mats = new_mats; }
+    free_dev(c->d_lights);
+    c->d_lights = new_lights;
+    c->n_lights = (uint32_t)lights.size();
     c->n = n;
     c->h_sph.assign(spheres, spheres + n);
     PT_HIP(c, hipMemcpyAsync(c->d_sph, spheres, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
@@ -1100,25 +1170,24 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
         std::memcpy(&m._pad[1], &inv_ior, 4);
     }
     PT_HIP(c, hipMemcpyAsync(c->d_mats, mats.data(), (size_t)n * sizeof(PtMaterial), hipMemcpyHostToDevice, c->stream));
-    // the emitters, in id order (LightPreparation::CountLights, Source/LightPreparation.ixx:52-70: objects with any emission > 0)
-    std::vector<uint32_t> lights;
-    for (uint32_t i = 0; i < n; i++) {
-        const PtMaterial& m = materials[i];
-        if (m.EmissiveStrength * m.EmissiveColor[0] > 0.0f || m.EmissiveStrength * m.EmissiveColor[1] > 0.0f || m.EmissiveStrength * m.EmissiveColor[2] > 0.0f)
-            lights.push_back(i);
-    }
-    free_dev(c->d_lights);
-    c->n_lights = (uint32_t)lights.size();
-    if (c->n_lights) {
-        PT_HIP(c, hipMalloc(&c->d_lights, lights.size() * sizeof(uint32_t)));
-        PT_HIP(c, hipMemcpyAsync(c->d_lights, lights.data(), lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    }
+    if (c->n_lights) PT_HIP(c, hipMemcpyAsync(c->d_lights, lights.data(), lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     PT_HIP(c, hipStreamSynchronize(c->stream));  // caller-owned host memory may be released on return
     c->sd = *sd;
     c->scene_set = true;
     c->accel_valid = false;
     c->scene_gen++;
     free_textures(c);  // texture maps are per sphere: a new scene starts untextured
+    // alpha-tested hits: the spheres that are not Opaque (Scene.ixx:242-243), classified now from their constant alpha and again when
+    // texture maps arrive (pt_set_textures)
+    c->alpha_mats.clear();
+    for (uint32_t i = 0; i < n && !empty; i++)
+        if (materials[i].AlphaMode != PT_ALPHA_OPAQUE) {
+            PtContext::AlphaMat am{};
+            am.id = i; am.cutoff = materials[i].AlphaCutoff; am.base_map = ~0u;
+            for (int k = 0; k < 4; k++) am.base[k] = materials[i].BaseColor[k];
+            c->alpha_mats.push_back(am);
+        }
+    if (PtStatus st = update_alpha_classes(c); st != PT_OK) return st;
     for (auto& L : c->lanes) { L.scene_private = false; L.upload_pending = false; L.needs_refit = false; L.sph_gen = 0; }  // every lane renders the new master scene
     c->sph_gen = 0;
     c->latest_lane = -1;
@@ -1198,6 +1267,7 @@ PtStatus pt_build_accel(PtContext* c, PtAccelInfo* info)
     }
     c->accel_valid = true;
     c->scene_gen++;
+    if (PtStatus st = refresh_leaf_ids(c); st != PT_OK) return st;
     if (info) {
         std::memset(info, 0, sizeof *info);
         info->leaf_count = c->empty_scene ? 0u : n;
@@ -1430,7 +1500,8 @@ PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_tex
     if (n_textures == 0) {  // drops the table
         PT_HIP(c, sync_all(c));
         free_textures(c);
-        return PT_OK;
+        for (auto& am : c->alpha_mats) am.base_map = ~0u;
+        return update_alpha_classes(c);
     }
     if (!textures) return fail(c, PT_ERR_INVALID_ARG, "pt_set_textures: null pointer");
     const uint32_t n = c->n;
@@ -1491,7 +1562,8 @@ PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_tex
     PT_HIP(c, hipMemcpy(c->d_rot, c->h_rot.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));  // (everything was synchronised above)
     c->rot_master_gen = ++c->rot_gen;  // the master copy is current; lanes take private copies from the next pt_update_rotations on
     c->has_textures = true;
-    return PT_OK;
+    for (auto& am : c->alpha_mats) am.base_map = maps[(size_t)am.id * 8u + kMapBaseColor];
+    return update_alpha_classes(c);  // a base-colour map turns a non-opaque sphere's alpha test into a per-crossing one
 }
 
 PtStatus pt_update_rotations(PtContext* c, const float* rotations, uint32_t n)

@@ -30,6 +30,17 @@ constexpr uint32_t kFlagDirty = 1u << 24;
 constexpr uint32_t kFlagViaTransmission = 1u << 25;  // row N4: this sample left the primary surface through the transmission lobe
 constexpr uint32_t kMissId = 0xFFFFFFFFu;
 
+// Alpha-tested hits (DESIGN.md spec S10; Scene.ixx:242-243, RaytracingHelpers.hlsli:19-43, ShadingHelpers.hlsli:105-115).  A sphere whose
+// AlphaMode is not Opaque is classified on the host when materials or texture maps change:
+//   kAlphaVisible    every crossing is accepted: Opaque, or constant alpha (no base-colour map is sampled) >= AlphaCutoff
+//   kAlphaInvisible  no crossing is accepted: constant alpha < AlphaCutoff (or NaN) -- the sphere does not exist for rays
+//   kAlphaTested     alpha = BaseColor.a * the base-colour map's alpha at the crossing: tested per crossing, near root then far root
+// The class rides in the two top bits of the leaf ids the traversal reads (SceneView::sorted_id; sphere ids stay below 2^30), so
+// a scene without such spheres pays one compare per successful sphere test and nothing else.
+enum : uint32_t { kAlphaVisible = 0u, kAlphaTested = 1u, kAlphaInvisible = 2u };
+constexpr uint32_t kIdMask = 0x3FFFFFFFu;
+constexpr uint32_t kIdClassShift = 30;
+
 // ---- scene view ------------------------------------------------------------------------------------
 // BVH node = 64 B = 4 float4 (PtBvhNode of include/pt_api.h):
 //   n0 = lo0.xyz, hi0.x   n1 = hi0.yz, lo1.xy   n2 = lo1.z, hi1.xyz   n3 = child0, child1, parent, pad (ints)
@@ -37,7 +48,7 @@ struct SceneView {
     const float4* nodes;        // n_nodes * 4
     const float4* wide;         // 4-wide quantised view of the tree (n_nodes * 4, pt_lbvh_gpu.hip collapse4_kernel) or null; global-memory scenes
     const float4* sph_sorted;   // Morton order {cx,cy,cz,r}
-    const uint32_t* sorted_id;  // Morton order -> original sphere id
+    const uint32_t* sorted_id;  // Morton order -> original sphere id | alpha class << 30 (kIdMask, kIdClassShift)
     const float4* sph;          // original order (shade)
     const float4* mats;         // original order, PtMaterial as 4 float4
     uint32_t n;                 // spheres
@@ -56,6 +67,10 @@ struct SceneView {
     // row N4 (sphere-light direct illumination): ids of the emissive spheres, in id order
     const uint32_t* lights;
     uint32_t n_lights;
+    // alpha-tested hits: per sphere (original order) its class, or null when every sphere is kAlphaVisible; alpha_tested = some
+    // sphere is kAlphaTested (only then do the kernels without a texture variant of their own need their kAlphaTex form)
+    const uint32_t* alpha_class;
+    uint32_t alpha_tested;
 };
 
 // ---- slot -> pixel mapping ---------------------------------------------------------------------------

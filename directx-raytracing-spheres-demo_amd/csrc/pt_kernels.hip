@@ -17,7 +17,7 @@
 namespace pt {
 
 // ------------------------------------------------------------------------------------------------ primary
-template <bool kLds, typename StackT>
+template <bool kLds, typename StackT, bool kAlphaTex>
 __global__ __launch_bounds__(kTraverseThreads) void primary_kernel(SceneView sv, PixelMap pm, FrameParams fp, RayQueue q,
                                                                    Scratch scratch, float4* __restrict__ out, FrameCounters fc)
 {
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kTraverseThreads) void primary_kernel(SceneView sv,
             float tmin, tmax;
             primary_ray(fp.cam, pr.px, pr.py, o, d, tmin, tmax);
             rng = rng_init(pr.px, pr.py, fp.frame_index);
-            closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, o, d, tmin, tmax, stack, blockDim.x, t, id, kLds ? nullptr : visits);
+            closest_hit_any<kLds, StackT, kAlphaTex>(sv, nodes, sph, ids, o, d, tmin, tmax, stack, blockDim.x, t, id, kLds ? nullptr : visits);
         } else if (pm.mode == 1) {
             // padding pixel of an edge tile (or a tile past the end): defined as zero
             // (out_index is always inside the packed buffer in tile mode)
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kTraverseThreads) void primary_kernel(SceneView sv,
 }
 
 // ------------------------------------------------------------------------------------------------ traverse
-template <bool kLds, typename StackT>
+template <bool kLds, typename StackT, bool kAlphaTex>
 __global__ __launch_bounds__(kTraverseThreads) void traverse_kernel(SceneView sv, RayQueue q, const uint32_t* __restrict__ count_ptr)
 {
     extern __shared__ float4 smem[];
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kTraverseThreads) void traverse_kernel(SceneView sv
         const float4 b = q.q1[i];
         float t;
         uint32_t id;
-        closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, make_f3(a.x, a.y, a.z), make_f3(b.x, b.y, b.z), 0.0f, kInf, stack, blockDim.x, t, id);
+        closest_hit_any<kLds, StackT, kAlphaTex>(sv, nodes, sph, ids, make_f3(a.x, a.y, a.z), make_f3(b.x, b.y, b.z), 0.0f, kInf, stack, blockDim.x, t, id);
         q.hit[i] = make_uint2(as_uint(t), id);
     }
 }
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kTraverseThreads) void traverse_kernel(SceneView sv
 // lane that finishes its ray is handed a new one as soon as fewer than kRefillBelow lanes of its wave are busy.
 constexpr uint32_t kRefillBelow = 44;
 
-template <typename StackT, bool kWide>
+template <typename StackT, bool kWide, bool kAlphaTex>
 __global__ __launch_bounds__(256) void traverse_dyn_kernel(SceneView sv, RayQueue q, const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ cursor,
                                                            unsigned long long* __restrict__ totals)
 {
@@ -189,8 +189,11 @@ __global__ __launch_bounds__(256) void traverse_dyn_kernel(SceneView sv, RayQueu
                 const float4 s = sph[k];
                 float t;
                 if (intersect_sphere(o, d, 0.0f, kInf, make_f3(s.x, s.y, s.z), s.w, t)) {
-                    const uint32_t id = ids[k];
-                    if (t < best || (t == best && best_id != kMissId && id < best_id)) { best = t; best_id = id; }
+                    const uint32_t idf = ids[k];
+                    if ((idf >> kIdClassShift) == 0u || alpha_candidate<kAlphaTex>(sv, idf, make_f3(s.x, s.y, s.z), s.w, o, d, t)) {
+                        const uint32_t id = idf & kIdMask;
+                        if (t < best || (t == best && best_id != kMissId && id < best_id)) { best = t; best_id = id; }
+                    }
                 }
                 if (sp == 0) finished = true;
                 else { sp -= stride; node = stack_decode(stack[sp]); }
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(SceneView sv, PixelM
         for (;;) {
             float t;
             uint32_t id;
-            closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, ps.o, ps.d, 0.0f, kInf, stack, blockDim.x, t, id, kLds ? nullptr : visits);
+            closest_hit_any<kLds, StackT, kTex>(sv, nodes, sph, ids, ps.o, ps.d, 0.0f, kInf, stack, blockDim.x, t, id, kLds ? nullptr : visits);
             if (!shade_step<true, kTex>(sv, pm, fp, scratch, out, ps, t, id)) break;
             my_rays++;  // rays spawned inside the tail (the input queue's rays are already in counts[])
         }
@@ -318,14 +321,14 @@ __global__ __launch_bounds__(kTraverseThreads) void di_kernel(SceneView sv, Pixe
             float tmin, tmax, t;
             uint32_t id;
             primary_ray(fp.cam, pr.px, pr.py, o, d, tmin, tmax);
-            closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, o, d, tmin, tmax, stack, blockDim.x, t, id);
+            closest_hit_any<kLds, StackT, kTex>(sv, nodes, sph, ids, o, d, tmin, tmax, stack, blockDim.x, t, id);
             // THE primary trace of this frame: the primary pass that follows reads the hit instead of tracing again (as the
             // reference's RTXDI passes and Raytracing.hlsl both start from the G-buffer); it is counted there (queue 0)
             primary_hit[slot] = make_uint2(as_uint(t), id);
             if (id != kMissId) {
                 const HitMaterial hm = hit_material<kTex>(sv, id, o, d, t, true);
                 est = di_estimate<kTex>(sv, fp, pr.px, pr.py, id, d, hm,
-                                        [&](f3 so, f3 sd, float& t2, uint32_t& id2) { closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, so, sd, 0.0f, kInf, stack, blockDim.x, t2, id2); },
+                                        [&](f3 so, f3 sd, float& t2, uint32_t& id2) { closest_hit_any<kLds, StackT, kTex>(sv, nodes, sph, ids, so, sd, 0.0f, kInf, stack, blockDim.x, t2, id2); },
                                         my_rays);
             }
         }
@@ -361,14 +364,14 @@ __global__ __launch_bounds__(kTraverseThreads) void trace_kernel(SceneView sv, c
         uint32_t v[2] = { 0, 0 };
         if (out_visits)
             if (!kLds && sv.wide)
-                closest_hit<StackT, true, true>(sv.wide, sph, ids, sv.n, make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
-                                                tmin, kInf, stack, blockDim.x, t, id, v);
+                closest_hit<StackT, true, true, true>(sv, sv.wide, sph, ids, sv.n, make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
+                                                      tmin, kInf, stack, blockDim.x, t, id, v);
             else
-            closest_hit<StackT, true>(nodes, sph, ids, sv.n, make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
-                                      tmin, kInf, stack, blockDim.x, t, id, v);
+                closest_hit<StackT, true, false, true>(sv, nodes, sph, ids, sv.n, make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
+                                                       tmin, kInf, stack, blockDim.x, t, id, v);
         else
-            closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
-                                tmin, kInf, stack, blockDim.x, t, id);
+            closest_hit_any<kLds, StackT, true>(sv, nodes, sph, ids, make_f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), make_f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
+                                                tmin, kInf, stack, blockDim.x, t, id);
         out_t[i] = t;
         out_id[i] = id;
         if (out_visits) out_visits[i] = make_uint2(v[0], v[1]);
@@ -385,7 +388,11 @@ __global__ void brute_kernel(SceneView sv, const float* __restrict__ o, const fl
         for (uint32_t k = 0; k < sv.n; k++) {
             const float4 s = sv.sph[k];
             float t;
-            if (intersect_sphere(oo, dd, tmin, best, make_f3(s.x, s.y, s.z), s.w, t)) { best = t; best_id = k; }
+            if (intersect_sphere(oo, dd, tmin, kInf, make_f3(s.x, s.y, s.z), s.w, t)) {
+                const uint32_t idf = k | (sv.alpha_class ? sv.alpha_class[k] << kIdClassShift : 0u);
+                if ((idf >> kIdClassShift) == 0u || alpha_candidate<true>(sv, idf, make_f3(s.x, s.y, s.z), s.w, oo, dd, t))
+                    if (t < best) { best = t; best_id = k; }
+            }
         }
         out_t[i] = best;
         out_id[i] = best_id;
@@ -459,6 +466,15 @@ __global__ void flush_counters_kernel(uint32_t* counts, uint32_t n_counts, unsig
     if (blockIdx.x == 0) fold_counters(counts, n_counts, tail, totals, host_counts);
 }
 
+// leaf ids the traversal reads: Morton order -> original id | alpha class << 30 (pt_device.h)
+__global__ void leaf_ids_kernel(const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ alpha_class, uint32_t n, uint32_t* __restrict__ out)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t id = sorted_id[k];
+        out[k] = id | (alpha_class[id] << kIdClassShift);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launch wrappers
 static uint32_t traverse_lds_bytes(const SceneView& sv, uint32_t stack_elem)
 {
@@ -473,34 +489,40 @@ uint32_t traverse_lds_bytes_for(uint32_t n_nodes, uint32_t n, uint32_t depth, bo
     return (lds_scene ? scene_lds_bytes(n_nodes, n) : 0u) + threads * depth * elem;
 }
 
-#define PT_DISPATCH_TRAVERSE(KERNEL, GRID, STREAM, ...)                                                        \
+// KERNEL<kLds, StackT, ...>: EXTRA = further template arguments (with their leading comma) or nothing
+#define PT_DISPATCH_TRAVERSE(KERNEL, EXTRA, GRID, STREAM, ...)                                                 \
     do {                                                                                                        \
         const bool small = sv.n_nodes < 32767u;                                                                 \
         const uint32_t lds = traverse_lds_bytes(sv, small ? 2u : 4u);                                           \
         if (lds + kStaticLdsMargin > 65536u) {                                                                                     \
-            const void* fn = sv.lds_scene ? (small ? (const void*)KERNEL<true, uint16_t> : (const void*)KERNEL<true, uint32_t>)   \
-                                          : (small ? (const void*)KERNEL<false, uint16_t> : (const void*)KERNEL<false, uint32_t>); \
+            const void* fn = sv.lds_scene ? (small ? (const void*)KERNEL<true, uint16_t EXTRA> : (const void*)KERNEL<true, uint32_t EXTRA>)   \
+                                          : (small ? (const void*)KERNEL<false, uint16_t EXTRA> : (const void*)KERNEL<false, uint32_t EXTRA>); \
             (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
         }                                                                                                       \
         if (sv.lds_scene) {                                                                                     \
-            if (small) hipLaunchKernelGGL((KERNEL<true, uint16_t>), dim3(GRID), dim3(traverse_threads(true)), lds, STREAM, __VA_ARGS__); \
-            else hipLaunchKernelGGL((KERNEL<true, uint32_t>), dim3(GRID), dim3(traverse_threads(true)), lds, STREAM, __VA_ARGS__);       \
+            if (small) hipLaunchKernelGGL((KERNEL<true, uint16_t EXTRA>), dim3(GRID), dim3(traverse_threads(true)), lds, STREAM, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<true, uint32_t EXTRA>), dim3(GRID), dim3(traverse_threads(true)), lds, STREAM, __VA_ARGS__);       \
         } else {                                                                                                \
-            if (small) hipLaunchKernelGGL((KERNEL<false, uint16_t>), dim3(GRID), dim3(traverse_threads(false)), lds, STREAM, __VA_ARGS__); \
-            else hipLaunchKernelGGL((KERNEL<false, uint32_t>), dim3(GRID), dim3(traverse_threads(false)), lds, STREAM, __VA_ARGS__);       \
+            if (small) hipLaunchKernelGGL((KERNEL<false, uint16_t EXTRA>), dim3(GRID), dim3(traverse_threads(false)), lds, STREAM, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<false, uint32_t EXTRA>), dim3(GRID), dim3(traverse_threads(false)), lds, STREAM, __VA_ARGS__);       \
         }                                                                                                       \
     } while (0)
+#define PT_COMMA_TRUE , true
+#define PT_COMMA_FALSE , false
 
 hipError_t launch_primary(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& q, const Scratch& scratch,
                           float4* out, const FrameCounters& fc, uint32_t grid, hipStream_t stream)
 {
-    PT_DISPATCH_TRAVERSE(primary_kernel, grid, stream, sv, pm, fp, q, scratch, out, fc);
+    // (the kAlphaTex form only when some sphere's hits are alpha-tested against a map)
+    if (sv.alpha_tested) PT_DISPATCH_TRAVERSE(primary_kernel, PT_COMMA_TRUE, grid, stream, sv, pm, fp, q, scratch, out, fc);
+    else PT_DISPATCH_TRAVERSE(primary_kernel, PT_COMMA_FALSE, grid, stream, sv, pm, fp, q, scratch, out, fc);
     return hipGetLastError();
 }
 
 hipError_t launch_traverse(const SceneView& sv, const RayQueue& q, const uint32_t* count_ptr, uint32_t grid, hipStream_t stream)
 {
-    PT_DISPATCH_TRAVERSE(traverse_kernel, grid, stream, sv, q, count_ptr);
+    if (sv.alpha_tested) PT_DISPATCH_TRAVERSE(traverse_kernel, PT_COMMA_TRUE, grid, stream, sv, q, count_ptr);
+    else PT_DISPATCH_TRAVERSE(traverse_kernel, PT_COMMA_FALSE, grid, stream, sv, q, count_ptr);
     return hipGetLastError();
 }
 
@@ -509,18 +531,16 @@ hipError_t launch_traverse_dyn(const SceneView& sv, const RayQueue& q, const uin
 {
     const bool small = sv.n_nodes < 32767u;
     const uint32_t lds = 256u * sv.stack_depth * (small ? 2u : 4u);
-    if (lds + kStaticLdsMargin > 65536u) {
-        const void* fn = sv.wide ? (small ? (const void*)traverse_dyn_kernel<uint16_t, true> : (const void*)traverse_dyn_kernel<uint32_t, true>)
-                                 : (small ? (const void*)traverse_dyn_kernel<uint16_t, false> : (const void*)traverse_dyn_kernel<uint32_t, false>);
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
-    if (sv.wide) {
-        if (small) hipLaunchKernelGGL((traverse_dyn_kernel<uint16_t, true>), dim3(grid), dim3(256), lds, stream, sv, q, count_ptr, cursor, totals);
-        else hipLaunchKernelGGL((traverse_dyn_kernel<uint32_t, true>), dim3(grid), dim3(256), lds, stream, sv, q, count_ptr, cursor, totals);
-    } else {
-        if (small) hipLaunchKernelGGL((traverse_dyn_kernel<uint16_t, false>), dim3(grid), dim3(256), lds, stream, sv, q, count_ptr, cursor, totals);
-        else hipLaunchKernelGGL((traverse_dyn_kernel<uint32_t, false>), dim3(grid), dim3(256), lds, stream, sv, q, count_ptr, cursor, totals);
-    }
+#define PT_DYN(T, W, A)                                                                                                          \
+    do {                                                                                                                          \
+        if (lds + kStaticLdsMargin > 65536u) (void)hipFuncSetAttribute((const void*)traverse_dyn_kernel<T, W, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((traverse_dyn_kernel<T, W, A>), dim3(grid), dim3(256), lds, stream, sv, q, count_ptr, cursor, totals);  \
+    } while (0)
+#define PT_DYN2(T, W) do { if (sv.alpha_tested) PT_DYN(T, W, true); else PT_DYN(T, W, false); } while (0)
+    if (sv.wide) { if (small) PT_DYN2(uint16_t, true); else PT_DYN2(uint32_t, true); }
+    else { if (small) PT_DYN2(uint16_t, false); else PT_DYN2(uint32_t, false); }
+#undef PT_DYN2
+#undef PT_DYN
     return hipGetLastError();
 }
 
@@ -590,7 +610,7 @@ hipError_t launch_trace(const SceneView& sv, const float* o, const float* d, uin
     const uint32_t grid = (n_rays + tt - 1) / tt < 2048u ? (n_rays + tt - 1) / tt : 2048u;
     if (grid == 0) return hipSuccess;
     if (use_bvh) {
-        PT_DISPATCH_TRAVERSE(trace_kernel, grid, stream, sv, o, d, n_rays, tmin, out_t, out_id, out_visits);
+        PT_DISPATCH_TRAVERSE(trace_kernel, , grid, stream, sv, o, d, n_rays, tmin, out_t, out_id, out_visits);
     } else {
         hipLaunchKernelGGL(brute_kernel, dim3(grid), dim3(kTraverseThreads), 0, stream, sv, o, d, n_rays, tmin, out_t, out_id);
     }
@@ -631,6 +651,13 @@ hipError_t launch_di(const SceneView& sv, const PixelMap& pm, const FrameParams&
     else { if (small) PT_DI(false, uint16_t); else PT_DI(false, uint32_t); }
 #undef PT_DI
 #undef PT_DI2
+    return hipGetLastError();
+}
+
+hipError_t launch_leaf_ids(const uint32_t* sorted_id, const uint32_t* alpha_class, uint32_t n, uint32_t* out, hipStream_t stream)
+{
+    const uint32_t grid = (n + 255u) / 256u < 4096u ? (n + 255u) / 256u : 4096u;
+    hipLaunchKernelGGL(leaf_ids_kernel, dim3(grid ? grid : 1u), dim3(256), 0, stream, sorted_id, alpha_class, n, out);
     return hipGetLastError();
 }
 

@@ -153,14 +153,62 @@ __device__ __forceinline__ void wide_visit(const float4* __restrict__ wide, int&
     }
 }
 
+// ------------------------------------------------------------------------------------------------ alpha-tested hits (spec S10)
+// texture coordinates of the point of sphere `id` whose outward world-space normal is N (spec S6): q = the object's rotation,
+// n_mesh = the mesh-space normal the coordinates (and the tangent) derive from
+__device__ __forceinline__ f2 hit_uv(const SceneView& sv, uint32_t id, f3 N, float4& q, f3& n_mesh)
+{
+    q = sv.rot[id];
+    const f3 n_obj = quat_rotate(-q.x, -q.y, -q.z, q.w, N);  // world -> object: the conjugate rotation
+    // ObjectToWorld = diag(1, 1, -1) * pose (Scene.ixx:197-199): the mesh-space normal is the z mirror of the object-space
+    // one (settled against the reference's screenshot with its own Earth map: without it the continents are mirrored)
+    n_mesh = make_f3(n_obj.x, n_obj.y, -n_obj.z);
+    return sphere_uv(n_mesh);
+}
+
+// IsOpaque (ShadingHelpers.hlsli:105-115) for the crossing at parameter t of a kAlphaTested sphere: alpha = BaseColor.a * the
+// base-colour map's alpha at the crossing's texture coordinates (the class says EvaluateBaseColor samples, :61-72); accepted iff
+// alpha >= AlphaCutoff.
+__device__ __forceinline__ bool crossing_is_opaque(const SceneView& sv, uint32_t id, f3 C, f3 o, f3 d, float t)
+{
+    const float base_alpha = sv.mats[id * 4 + 0].w, cutoff = sv.mats[id * 4 + 3].y;
+    const uint32_t map = sv.tex_maps[(size_t)id * 8u + kMapBaseColor];
+    const f3 N = normalize(mad(t, d, o) - C);  // the hit frame's normal
+    float4 q;
+    f3 n_mesh;
+    const f2 uv = hit_uv(sv, id, N, q, n_mesh);
+    float s[4];
+    sample_bilinear(sv.tex[map], uv, s);
+    return base_alpha * s[3] >= cutoff;
+}
+
+// A sphere test succeeded at t for the leaf with flagged id `idf` whose class bits are set (rare): does the sphere offer an
+// accepted crossing?  kAlphaInvisible: never.  kAlphaTested: the crossing at t, else the one behind it ("the next crossing" =
+// intersect_sphere with tmin = the rejected t: the far root, seen from inside); t returns the accepted one.  kAlphaTex = false
+// (kernels of scenes without textures, where the class cannot occur): accepted.
+template <bool kAlphaTex>
+__device__ __forceinline__ bool alpha_candidate(const SceneView& sv, uint32_t idf, f3 C, float r, f3 o, f3 d, float& t)
+{
+    if ((idf >> kIdClassShift) == kAlphaInvisible) return false;
+    if (!kAlphaTex) return true;
+    const uint32_t id = idf & kIdMask;
+    for (;;) {
+        if (crossing_is_opaque(sv, id, C, o, d, t)) return true;
+        float t2;
+        if (!intersect_sphere(o, d, t, kInf, C, r, t2)) return false;
+        t = t2;
+    }
+}
+
 // Closest hit over the LBVH ("while-while" traversal: descend internal nodes until every lane of the wave holds a
 // leaf or has finished, then run the sphere tests together).  nodes/sph/ids may live in LDS or global memory (the
 // address space is inferred after inlining).  stack: per-lane stack, entry e of lane l at stack[e * stride + l].
 // The result is identical to brute force: nearest t, ties -> lowest original id (leaf boxes are padded so the slab
 // test is conservative w.r.t. intersect_sphere; culling is <=).
 // kWide: `nodes` is the 4-wide view of the tree (128-byte records, wide_visit) instead of the binary records.
-template <typename StackT, bool kCount = false, bool kWide = false>
-__device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, const float4* __restrict__ sph,
+// kAlphaTex: the per-crossing alpha test of kAlphaTested spheres is compiled in (alpha_candidate).
+template <typename StackT, bool kCount = false, bool kWide = false, bool kAlphaTex = false>
+__device__ __forceinline__ void closest_hit(const SceneView& sv, const float4* __restrict__ nodes, const float4* __restrict__ sph,
                                             const uint32_t* __restrict__ ids, uint32_t n, f3 o, f3 d, float tmin, float tmax,
                                             StackT* stack, uint32_t stride, float& t_out, uint32_t& id_out, uint32_t* visits = nullptr, uint32_t descent_cap = 0)
 {
@@ -170,7 +218,11 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
     if (n == 1) {
         float4 s = sph[0];
         float t;
-        if (intersect_sphere(o, d, tmin, best, make_f3(s.x, s.y, s.z), s.w, t)) { best = t; best_id = ids[0]; }
+        if (intersect_sphere(o, d, tmin, kInf, make_f3(s.x, s.y, s.z), s.w, t)) {
+            const uint32_t idf = ids[0];
+            if ((idf >> kIdClassShift) == 0u || alpha_candidate<kAlphaTex>(sv, idf, make_f3(s.x, s.y, s.z), s.w, o, d, t))
+                if (t < best) { best = t; best_id = idf & kIdMask; }
+        }
         t_out = best; id_out = best_id;
         return;
     }
@@ -228,8 +280,11 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
             const float4 s = sph[k];
             float t;
             if (intersect_sphere(o, d, tmin, kInf, make_f3(s.x, s.y, s.z), s.w, t)) {
-                const uint32_t id = ids[k];
-                if (t < best || (t == best && best_id != kMissId && id < best_id)) { best = t; best_id = id; }
+                const uint32_t idf = ids[k];
+                if ((idf >> kIdClassShift) == 0u || alpha_candidate<kAlphaTex>(sv, idf, make_f3(s.x, s.y, s.z), s.w, o, d, t)) {
+                    const uint32_t id = idf & kIdMask;
+                    if (t < best || (t == best && best_id != kMissId && id < best_id)) { best = t; best_id = id; }
+                }
             }
         }
         if (sp == 0) break;
@@ -243,19 +298,19 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
 
 // closest_hit through whichever view of the tree the scene offers: the LDS copy (binary records) when kLds, else the 4-wide view
 // when the scene has one (SceneView::wide), else the binary records in global memory
-template <bool kLds, typename StackT>
+template <bool kLds, typename StackT, bool kAlphaTex = false>
 __device__ __forceinline__ void closest_hit_any(const SceneView& sv, const float4* __restrict__ nodes, const float4* __restrict__ sph,
                                                 const uint32_t* __restrict__ ids, f3 o, f3 d, float tmin, float tmax, StackT* stack, uint32_t stride,
                                                 float& t_out, uint32_t& id_out, uint32_t* visits = nullptr)
 {
     // visits (global-memory scenes): this lane's running {node visits, sphere tests}, the scene term of SURVEY 8(d)'s byte accounting
     if (!kLds && visits) {
-        if (sv.wide) closest_hit<StackT, true, true>(sv.wide, sph, ids, sv.n, o, d, tmin, tmax, stack, stride, t_out, id_out, visits, sv.descent_cap);
-        else closest_hit<StackT, true>(nodes, sph, ids, sv.n, o, d, tmin, tmax, stack, stride, t_out, id_out, visits, sv.descent_cap);
+        if (sv.wide) closest_hit<StackT, true, true, kAlphaTex>(sv, sv.wide, sph, ids, sv.n, o, d, tmin, tmax, stack, stride, t_out, id_out, visits, sv.descent_cap);
+        else closest_hit<StackT, true, false, kAlphaTex>(sv, nodes, sph, ids, sv.n, o, d, tmin, tmax, stack, stride, t_out, id_out, visits, sv.descent_cap);
     } else if (!kLds && sv.wide) {
-        closest_hit<StackT, false, true>(sv.wide, sph, ids, sv.n, o, d, tmin, tmax, stack, stride, t_out, id_out, nullptr, sv.descent_cap);
+        closest_hit<StackT, false, true, kAlphaTex>(sv, sv.wide, sph, ids, sv.n, o, d, tmin, tmax, stack, stride, t_out, id_out, nullptr, sv.descent_cap);
     } else {
-        closest_hit<StackT>(nodes, sph, ids, sv.n, o, d, tmin, tmax, stack, stride, t_out, id_out, nullptr, sv.descent_cap);
+        closest_hit<StackT, false, false, kAlphaTex>(sv, nodes, sph, ids, sv.n, o, d, tmin, tmax, stack, stride, t_out, id_out, nullptr, sv.descent_cap);
     }
 }
 
@@ -403,17 +458,21 @@ __global__ __launch_bounds__(256) void beam_kernel(SceneView sv, PixelMap pm, Fr
 
 // Closest hit of a primary ray over its block's candidate list (wave-uniform loop; sphere records come through the scalar
 // cache).  Same intersect_sphere, same tie rule as closest_hit's leaves.
+template <bool kAlphaTex = false>
 __device__ __forceinline__ void closest_hit_list(const SceneView& sv, const uint32_t* __restrict__ rec, uint32_t count, f3 o, f3 d, float tmin, float tmax,
                                                  float& t_out, uint32_t& id_out)
 {
     float best = tmax;
     uint32_t best_id = kMissId;
     for (uint32_t j = 0; j < count; j++) {
-        const uint32_t id = __builtin_amdgcn_readfirstlane(rec[1 + j]);
+        const uint32_t idf = __builtin_amdgcn_readfirstlane(rec[1 + j]);  // (the list carries the leaf ids with their alpha class)
+        const uint32_t id = idf & kIdMask;
+        if ((idf >> kIdClassShift) == kAlphaInvisible) continue;  // wave-uniform
         const float4 s = sv.sph[id];
         float t;
         if (intersect_sphere(o, d, tmin, kInf, make_f3(s.x, s.y, s.z), s.w, t)) {
-            if (t < best || (t == best && best_id != kMissId && id < best_id)) { best = t; best_id = id; }
+            if ((idf >> kIdClassShift) == 0u || alpha_candidate<kAlphaTex>(sv, idf, make_f3(s.x, s.y, s.z), s.w, o, d, t))
+                if (t < best || (t == best && best_id != kMissId && id < best_id)) { best = t; best_id = id; }
         }
     }
     t_out = best; id_out = best_id;
@@ -455,12 +514,9 @@ __device__ __forceinline__ HitMaterial hit_material(const SceneView& sv, uint32_
         const uint4 ma = mp[0], mb = mp[1];
         if (mb.w) {  // this sphere has at least one texture map
             const uint32_t maps[kMapCount] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z };
-            const float4 q = sv.rot[id];
-            const f3 n_obj = quat_rotate(-q.x, -q.y, -q.z, q.w, r.hf.N);  // world -> object: the conjugate rotation
-            // ObjectToWorld = diag(1, 1, -1) * pose (Scene.ixx:197-199): the mesh-space normal is the z mirror of the object-space
-            // one (settled against the reference's screenshot with its own Earth map: without it the continents are mirrored)
-            const f3 n_mesh = make_f3(n_obj.x, n_obj.y, -n_obj.z);
-            const f2 uv = sphere_uv(n_mesh);
+            float4 q;
+            f3 n_mesh;
+            const f2 uv = hit_uv(sv, id, r.hf.N, q, n_mesh);
             const f3 t_mesh = sphere_tangent(n_mesh);
             f3 T = quat_rotate(q.x, q.y, q.z, q.w, make_f3(t_mesh.x, t_mesh.y, -t_mesh.z));
             if (!r.hf.front) T = -T;  // HitInfo::GetFrontTangent
@@ -849,16 +905,16 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
                     float t;
                     uint32_t id;
                     if (kPrimary && primary_trace && fp.beam_lists && beam_count <= kBeamListCap) {
-                        closest_hit_list(sv, beam_rec, beam_count, ps.o, ps.d, tmin, tmax, t, id);
+                        closest_hit_list<kTex>(sv, beam_rec, beam_count, ps.o, ps.d, tmin, tmax, t, id);
                         if (kMulti) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
                     } else {
-                        closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, ps.o, ps.d, tmin, tmax, stack, blockDim.x, t, id);
+                        closest_hit_any<kLds, StackT, kTex>(sv, nodes, sph, ids, ps.o, ps.d, tmin, tmax, stack, blockDim.x, t, id);
                         if (kMulti && kPrimary && primary_trace) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
                     }
                     primary_trace = false;
                     if (kDI)  // row N4: the first shading of the primary surface also makes its direct-illumination estimate
                         emit = shade_step<kMulti, kTex, true>(sv, pm, fp, scratch, out, ps, t, id,
-                                                              [&](f3 so, f3 sd, float& t2, uint32_t& id2) { closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, so, sd, 0.0f, kInf, stack, blockDim.x, t2, id2); },
+                                                              [&](f3 so, f3 sd, float& t2, uint32_t& id2) { closest_hit_any<kLds, StackT, kTex>(sv, nodes, sph, ids, so, sd, 0.0f, kInf, stack, blockDim.x, t2, id2); },
                                                               &my_rays);
                     else
                         emit = shade_step<kMulti, kTex>(sv, pm, fp, scratch, out, ps, t, id);
@@ -921,7 +977,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
                     for (;;) {
                         float t;
                         uint32_t id;
-                        closest_hit_any<kLds, StackT>(sv, nodes, sph, ids, ps.o, ps.d, 0.0f, kInf, stack, blockDim.x, t, id);
+                        closest_hit_any<kLds, StackT, kTex>(sv, nodes, sph, ids, ps.o, ps.d, 0.0f, kInf, stack, blockDim.x, t, id);
                         if (!shade_step<kMulti, kTex>(sv, pm, fp, scratch, out, ps, t, id)) break;
                         my_loop_rays++;
                     }

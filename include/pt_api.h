@@ -121,7 +121,12 @@ PtStatus pt_create(const PtConfig *config, PtContext **out_ctx);
 void pt_destroy(PtContext *ctx);
 
 /* Copies n spheres + n materials (material i belongs to sphere i == ObjectIndex) and the scene constants.  n == 0 is a legal scene
- * (a TLAS without instances; the pointers may be NULL): every ray misses and every pixel is the environment. */
+ * (a TLAS without instances; the pointers may be NULL): every ray misses and every pixel is the environment.
+ * Materials whose AlphaMode is not Opaque make their sphere non-opaque geometry, as Scene::CreateAccelerationStructures does
+ * (Source/Scene.ixx:242-243): every closest-hit query of the path (primary, bounce and shadow rays, pt_trace_rays) then runs
+ * TraceRay's candidate loop for it (Shaders/RaytracingHelpers.hlsli:19-43) -- a crossing of the ray with the sphere's surface counts
+ * only if IsOpaque accepts it: BaseColor.a, times the alpha of the base-colour map at that crossing once pt_set_textures has
+ * given the sphere one, >= AlphaCutoff; the near crossing is tried first, then the far one (DESIGN.md spec S10). */
 PtStatus pt_set_scene(PtContext *ctx, const PtSphere *spheres, const PtMaterial *materials, uint32_t n,
                       const PtSceneData *scene_data);
 /* Builds the LBVH over the current spheres.  info may be NULL. */

@@ -42,8 +42,9 @@ typedef struct PtMaterial {
     float Roughness;         /* 36 */
     float IOR;               /* 40 */
     float Transmission;      /* 44 */
-    uint32_t AlphaMode;      /* 48 */
-    float AlphaCutoff;       /* 52 */
+    uint32_t AlphaMode;      /* 48: not Opaque = non-opaque geometry (Source/Scene.ixx:242-243): every crossing of a ray with the sphere */
+    float AlphaCutoff;       /* 52: is a candidate that counts only if BaseColor.a (times the base-colour map's alpha) >= AlphaCutoff --
+                                    Mask and Blend alike (Shaders/RaytracingHelpers.hlsli:19-43, ShadingHelpers.hlsli:105-115) */
     uint32_t _pad[2];        /* 56 */
 } PtMaterial;
 

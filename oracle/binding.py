@@ -91,6 +91,8 @@ class Oracle:
         lib.oracle_sample_texture.argtypes = [vp, u32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         lib.oracle_closest_hit.restype = C.c_int
         lib.oracle_closest_hit.argtypes = [vp, u32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int, C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(u32)]
+        lib.oracle_closest_hit_alpha.restype = C.c_int
+        lib.oracle_closest_hit_alpha.argtypes = [vp, vp, u32, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(u32)]
         lib.oracle_free_bvh.restype = None
         lib.oracle_free_bvh.argtypes = [vp]
         lib.oracle_tonemap.restype = None
@@ -144,6 +146,20 @@ class Oracle:
             t[i], ids[i] = tt.value, ii.value
         if cache.value:
             self.lib.oracle_free_bvh(cache)
+        return t, ids
+
+    def closest_hits_alpha(self, spheres, materials, origins, directions, tmin=0.0, tmax=float("inf"), textures=None):
+        """closest hit of every ray with alpha-tested hits (spec S10), brute force: (t float32[n], id uint32[n])"""
+        spheres = np.ascontiguousarray(spheres); materials = np.ascontiguousarray(materials)
+        o = np.ascontiguousarray(origins, dtype=np.float32); d = np.ascontiguousarray(directions, dtype=np.float32)
+        t = np.zeros(len(o), dtype=np.float32); ids = np.zeros(len(o), dtype=np.uint32)
+        pf = C.POINTER(C.c_float)
+        tex, keep = (self._textures_struct(textures) if textures is not None else (None, None))
+        for i in range(len(o)):
+            tt, ii = C.c_float(), C.c_uint32()
+            self.lib.oracle_closest_hit_alpha(spheres.ctypes.data, materials.ctypes.data, len(spheres), C.addressof(tex) if tex is not None else None,
+                                              o[i].ctypes.data_as(pf), d[i].ctypes.data_as(pf), tmin, tmax, C.byref(tt), C.byref(ii))
+            t[i], ids[i] = tt.value, ii.value
         return t, ids
 
     def tonemap(self, hdr, params):

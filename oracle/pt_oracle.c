@@ -486,14 +486,40 @@ static int obvh_hits_box(const onode *nd, const double o[3], const double inv[3]
     return t0 <= t1 * (1.0 + 1e-12) + 1e-300;
 }
 
-static void closest_hit_id(const obvh *b, const PtSphere *sph, uint32_t n, v3 o, v3 d, float tmin, float tmax, float *best_t, uint32_t *best_id)
+/* ------------------------------------------------------------------------------------------------------------------
+ * Alpha-tested hits (spec S10).  The reference flags the geometry of an object whose AlphaMode is not Opaque as non-opaque
+ * (Source/Scene.ixx:242-243); TraceRay then commits a candidate of such an object only if IsOpaque says so
+ * (Shaders/RaytracingHelpers.hlsli:19-43): alpha = BaseColor.a, times the alpha of the base-colour map at the candidate's
+ * texture coordinates when EvaluateBaseColor's condition holds (any(BaseColor > 0) and a map, Shaders/ShadingHelpers.hlsli:61-72),
+ * accepted iff alpha >= AlphaCutoff (:105-115) -- Mask and Blend alike.  A candidate there is a triangle; here it is one
+ * crossing of the ray with the sphere's surface: the near root of the quadratic, then the far one (the back of the sphere seen
+ * from inside), each tested at its own texture coordinates.  "The next crossing" = intersect_sphere with tmin = the rejected t.
+ * ---------------------------------------------------------------------------------------------------------------- */
+struct tex_ctx_s;
+typedef struct { const PtMaterial *mat; const struct tex_ctx_s *tc; } alpha_ctx;
+static int crossing_is_opaque(const alpha_ctx *a, const PtSphere *s, uint32_t id, v3 o, v3 d, float t);
+static size_t sizeof_tex_ctx(void);
+static void tex_ctx_init_opaque(struct tex_ctx_s *c, const OracleTextures *t);
+
+/* the first crossing of sphere `id` in (tmin, tmax) that the alpha test accepts; a == NULL: every sphere is opaque */
+static int sphere_candidate(const alpha_ctx *a, v3 o, v3 d, float tmin, float tmax, const PtSphere *s, uint32_t id, float *t_out)
+{
+    float tm = tmin, t;
+    while (intersect_sphere(o, d, tm, tmax, s, &t)) {
+        if (!a || a->mat[id].AlphaMode == PT_ALPHA_OPAQUE || crossing_is_opaque(a, s, id, o, d, t)) { *t_out = t; return 1; }
+        tm = t; /* rejected: on to the crossing behind it */
+    }
+    return 0;
+}
+
+static void closest_hit_id(const obvh *b, const PtSphere *sph, uint32_t n, v3 o, v3 d, float tmin, float tmax, float *best_t, uint32_t *best_id, const alpha_ctx *alpha)
 {
     float best = tmax;
     uint32_t id = 0xFFFFFFFFu;
     if (!b) {
         for (uint32_t i = 0; i < n; i++) {
             float t;
-            if (intersect_sphere(o, d, tmin, best, &sph[i], &t)) { best = t; id = i; }
+            if (sphere_candidate(alpha, o, d, tmin, best, &sph[i], i, &t)) { best = t; id = i; }
         }
     } else {
         const double oo[3] = { o.x, o.y, o.z };
@@ -509,7 +535,7 @@ static void closest_hit_id(const obvh *b, const PtSphere *sph, uint32_t n, v3 o,
                     const uint32_t i = b->prim[k];
                     float t;
                     /* same acceptance as the brute-force loop: inside (tmin, tmax); nearer wins, ties go to the lower id */
-                    if (intersect_sphere(o, d, tmin, tmax, &sph[i], &t) && (t < best || (t == best && id != 0xFFFFFFFFu && i < id))) { best = t; id = i; }
+                    if (sphere_candidate(alpha, o, d, tmin, tmax, &sph[i], i, &t) && (t < best || (t == best && id != 0xFFFFFFFFu && i < id))) { best = t; id = i; }
                 }
             } else if (sp + 2 <= 128) {
                 stack[sp++] = nd->left; stack[sp++] = nd->right;
@@ -519,11 +545,11 @@ static void closest_hit_id(const obvh *b, const PtSphere *sph, uint32_t n, v3 o,
     *best_t = best; *best_id = id;
 }
 
-static void cast_ray(const void *accel, const PtSphere *sph, uint32_t n, v3 o, v3 d, float tmin, float tmax, hit_t *h)
+static void cast_ray(const void *accel, const PtSphere *sph, uint32_t n, v3 o, v3 d, float tmin, float tmax, hit_t *h, const alpha_ctx *alpha)
 {
     float best;
     uint32_t best_id;
-    closest_hit_id((const obvh *)accel, sph, n, o, d, tmin, tmax, &best, &best_id);
+    closest_hit_id((const obvh *)accel, sph, n, o, d, tmin, tmax, &best, &best_id, alpha);
     h->hit = best_id != 0xFFFFFFFFu;
     h->id = best_id;
     h->t = best;
@@ -550,11 +576,24 @@ int oracle_closest_hit(const PtSphere *spheres, uint32_t n, const float o[3], co
         if (bvh_cache && *bvh_cache) b = (obvh *)*bvh_cache;
         else { b = obvh_build(spheres, n); if (bvh_cache) *bvh_cache = b; }
     }
-    closest_hit_id(b, spheres, n, V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), tmin, tmax, t, id);
+    closest_hit_id(b, spheres, n, V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), tmin, tmax, t, id, NULL);
     if (use_bvh && !bvh_cache) obvh_free(b);
     return *id != 0xFFFFFFFFu;
 }
 void oracle_free_bvh(void *bvh) { obvh_free((obvh *)bvh); }
+
+/* the same query with alpha-tested hits (spec S10): materials carry AlphaMode / AlphaCutoff / BaseColor, textures (may be NULL)
+ * the base-colour maps and rotations.  Brute force only (the definition). */
+int oracle_closest_hit_alpha(const PtSphere *spheres, const PtMaterial *materials, uint32_t n, const OracleTextures *textures,
+                             const float o[3], const float d[3], float tmin, float tmax, float *t, uint32_t *id)
+{
+    struct tex_ctx_s *tc = NULL;
+    if (textures && textures->n_textures > 0) { tc = (struct tex_ctx_s *)malloc(sizeof_tex_ctx()); tex_ctx_init_opaque(tc, textures); }
+    const alpha_ctx a = { materials, tc };
+    closest_hit_id(NULL, spheres, n, V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), tmin, tmax, t, id, &a);
+    free(tc);
+    return *id != 0xFFFFFFFFu;
+}
 
 void oracle_hit_frame(const float o[3], const float d[3], float t, const PtSphere *s,
                       float P[3], float N[3], float *offset, int *front)
@@ -821,6 +860,9 @@ static void tex_ctx_init(tex_ctx *c, const OracleTextures *t)
     }
 }
 
+static size_t sizeof_tex_ctx(void) { return sizeof(tex_ctx); }
+static void tex_ctx_init_opaque(struct tex_ctx_s *c, const OracleTextures *t) { tex_ctx_init(c, t); }
+
 float oracle_atan2(float y, float x)
 {
     float ax = f_abs(x), ay = f_abs(y);
@@ -988,6 +1030,42 @@ void oracle_perturb_normal(const float N[3], const float T[3], float sx, float s
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 
+/* texture coordinates of the point of sphere `id` whose outward world-space normal is N (spec S6); also returns the object's
+ * rotation q and the mesh-space normal nn */
+static void hit_uv(const tex_ctx *tc, uint32_t id, v3 N, float q[4], float nn[3], float uv[2])
+{
+    q[0] = 0; q[1] = 0; q[2] = 0; q[3] = 1;
+    if (tc->t->rotations) memcpy(q, tc->t->rotations + 4u * (size_t)id, 4 * sizeof(float));
+    v3 n_obj = quat_rotate(-q[0], -q[1], -q[2], q[3], N); /* world -> object */
+    /* ObjectToWorld = diag(1, 1, -1) * pose (Scene.ixx:197-199): the mesh-space normal is the z mirror of the object-space one (the
+     * rotations handed over are the poses conjugated with that mirror).  Settled against Screenshots/Raytracing-Spheres.png with the
+     * reference's own Earth map: without the mirror the continents come out mirrored. */
+    nn[0] = n_obj.x; nn[1] = n_obj.y; nn[2] = -n_obj.z;
+    oracle_sphere_uv(nn, uv);
+}
+
+/* IsOpaque (ShadingHelpers.hlsli:105-115) for the crossing at parameter t of sphere `id` (AlphaMode != Opaque): alpha =
+ * BaseColor.a, times the base-colour map's alpha at the crossing when EvaluateBaseColor samples (:61-72: any component of the
+ * float4 BaseColor > 0 and a map); accepted iff alpha >= AlphaCutoff (NaN: rejected). */
+static int crossing_is_opaque(const alpha_ctx *a, const PtSphere *sp, uint32_t id, v3 o, v3 d, float t)
+{
+    const PtMaterial *m = &a->mat[id];
+    float alpha = m->BaseColor[3];
+    const tex_ctx *tc = a->tc;
+    if (tc && tc->t->object_textures) {
+        const uint32_t desc = tc->t->object_textures[id].Maps[PT_TEXTURE_MAP_BASE_COLOR].Descriptor;
+        if (desc != ~0u && (m->BaseColor[0] > 0.0f || m->BaseColor[1] > 0.0f || m->BaseColor[2] > 0.0f || m->BaseColor[3] > 0.0f)) {
+            v3 C = V3(sp->cx, sp->cy, sp->cz);
+            v3 N = v_normalize(v_sub(v_mad(t, d, o), C)); /* the hit frame's normal (cast_ray) */
+            float q[4], nn[3], uv[2], s[4];
+            hit_uv(tc, id, N, q, nn, uv);
+            sample_bilinear(tc, desc, uv, s);
+            alpha = alpha * s[3];
+        }
+    }
+    return alpha >= m->AlphaCutoff;
+}
+
 typedef struct {
     v3 base, emissive_color;
     float emissive_strength, metallic, roughness, ior, transmission;
@@ -1010,14 +1088,8 @@ static material_eval evaluate_material(const tex_ctx *tc, const PtMaterial *m, c
     for (int k = 0; k < PT_TEXTURE_MAP_COUNT; k++) any |= maps[k].Descriptor != ~0u;
     if (!any) return e;
 
-    float q[4] = { 0, 0, 0, 1 };
-    if (tc->t->rotations) memcpy(q, tc->t->rotations + 4u * (size_t)h->id, sizeof q);
-    v3 n_obj = quat_rotate(-q[0], -q[1], -q[2], q[3], h->N); /* world -> object */
-    /* ObjectToWorld = diag(1, 1, -1) * pose (Scene.ixx:197-199): the mesh-space normal is the z mirror of the object-space one (the
-     * rotations handed over are the poses conjugated with that mirror).  Settled against Screenshots/Raytracing-Spheres.png with the
-     * reference's own Earth map: without the mirror the continents come out mirrored. */
-    float nn[3] = { n_obj.x, n_obj.y, -n_obj.z }, uv[2], s[4];
-    oracle_sphere_uv(nn, uv);
+    float q[4], nn[3], uv[2], s[4];
+    hit_uv(tc, h->id, h->N, q, nn, uv);
     v3 t_mesh = sphere_tangent(V3(nn[0], nn[1], nn[2]));
     v3 T = quat_rotate(q[0], q[1], q[2], q[3], V3(t_mesh.x, t_mesh.y, -t_mesh.z));
     if (!h->front) T = v_neg(T); /* GetFrontTangent */
@@ -1096,7 +1168,7 @@ int oracle_sample_sphere_cone(const float P[3], const float C[3], float r, float
 static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_t n,
                              const PtSceneData *sd, const PtCamera *cam, const PtGraphicsSettings *gs,
                              uint32_t px, uint32_t py, float rgba[4], uint64_t *paths_out, trace_t *tr, const tex_ctx *tc,
-                             const light_list *lights, const void *accel)
+                             const light_list *lights, const void *accel, int has_alpha)
 {
     (void)paths_out;
     uint64_t rays = 0;
@@ -1104,9 +1176,13 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
     v3 o, d; float tmin, tmax;
     primary_ray(cam, px, py, gs->RenderSize[0], gs->RenderSize[1], &o, &d, &tmin, &tmax); /* :138 */
 
+    /* alpha-tested hits (spec S10) only exist when some object is not Opaque */
+    const alpha_ctx actx = { mat, tc };
+    const alpha_ctx *alpha = has_alpha ? &actx : NULL;
+
     /* primary-hit pass (GBufferGeneration.hlsl:128-230) */
     hit_t primary;
-    cast_ray(accel, sph, n, o, d, tmin, tmax, &primary);
+    cast_ray(accel, sph, n, o, d, tmin, tmax, &primary, alpha);
     rays++;
     const int di_on = gs->IsDIEnabled && lights && lights->n > 0;
     if (!primary.hit) { /* miss: Radiance = env (GBufferGeneration.hlsl:223-227); bounce loop returns without writing (:249-252) */
@@ -1150,7 +1226,7 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
             hit_t sh;
             sh.hit = 0;
             if (bound > DI_NEGLIGIBLE) {
-                cast_ray(accel, sph, n, spawn_origin(primary.P, primary.N, primary.offset, L), L, 0.0f, INFINITY, &sh);
+                cast_ray(accel, sph, n, spawn_origin(primary.P, primary.N, primary.offset, L), L, 0.0f, INFINITY, &sh, alpha);
                 rays++;
             }
             if (sh.hit && sh.id == light) {
@@ -1183,7 +1259,7 @@ static uint64_t render_pixel(const PtSphere *sph, const PtMaterial *mat, uint32_
             if (bnc) { /* :219-234 */
                 ro = spawn_origin(hit.P, hit.N, hit.offset, L);
                 rd = L;
-                cast_ray(accel, sph, n, ro, rd, 0.0f, INFINITY, &hit);
+                cast_ray(accel, sph, n, ro, rd, 0.0f, INFINITY, &hit, alpha);
                 is_hit = hit.hit;
                 rays++;
             }
@@ -1246,6 +1322,7 @@ typedef struct {
     const void *tex; /* tex_ctx */
     const void *lights; /* light_list */
     const void *accel;  /* obvh or NULL (brute force) */
+    int has_alpha;      /* some object's AlphaMode is not Opaque */
     int tid, nthreads;
     uint64_t rays, paths;
 } job_t;
@@ -1326,7 +1403,7 @@ static void *worker(void *arg)
         if ((int)(k % (uint32_t)j->nthreads) != j->tid) continue;
         for (uint32_t rx = 0; rx < j->rect.w; rx++) {
             float *px = j->out + 4 * ((size_t)ry * j->rect.w + rx);
-            j->rays += render_pixel(j->sph, j->mat, j->n, j->sd, j->cam, j->gs, j->rect.x + rx, j->rect.y + ry, px, &j->paths, NULL, (const tex_ctx *)j->tex, (const light_list *)j->lights, j->accel);
+            j->rays += render_pixel(j->sph, j->mat, j->n, j->sd, j->cam, j->gs, j->rect.x + rx, j->rect.y + ry, px, &j->paths, NULL, (const tex_ctx *)j->tex, (const light_list *)j->lights, j->accel, j->has_alpha);
             j->paths += j->gs->SamplesPerPixel; /* nominal (pixel, sample) pairs */
         }
     }
@@ -1373,6 +1450,7 @@ int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials,
     int err = validate(scene, gs, n);
     if (err) return err;
     if ((err = validate_textures(textures, n)) != 0) return err;
+    if (rect->x + rect->w > gs->RenderSize[0] || rect->y + rect->h > gs->RenderSize[1]) return 5;
     if (scene->EnvironmentLightTextureDescriptor != 0xFFFFFFFFu) { /* the descriptor indexes the texture table; a cube map = 6 square faces */
         const uint32_t e = scene->EnvironmentLightTextureDescriptor, nf = scene->IsEnvironmentLightTextureCubeMap ? 6u : 1u;
         if (!textures || (uint64_t)e + nf > textures->n_textures) return 4;
@@ -1413,7 +1491,8 @@ int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials,
         if (m->EmissiveStrength * m->EmissiveColor[0] > 0.0f || m->EmissiveStrength * m->EmissiveColor[1] > 0.0f || m->EmissiveStrength * m->EmissiveColor[2] > 0.0f)
             light_ids[ll.n++] = i;
     }
-    if (rect->x + rect->w > gs->RenderSize[0] || rect->y + rect->h > gs->RenderSize[1]) return 5;
+    int has_alpha = 0;
+    for (uint32_t i = 0; i < n && !has_alpha; i++) has_alpha = materials[i].AlphaMode != PT_ALPHA_OPAQUE;
     if (row_step == 0) row_step = 1;
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
@@ -1426,6 +1505,7 @@ int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials,
         j->tex = textured ? &tc : NULL;
         j->lights = &ll;
         j->accel = accel;
+        j->has_alpha = has_alpha;
     }
     if (threads == 1) worker(&jobs[0]);
     else {
@@ -1449,7 +1529,9 @@ int oracle_trace_pixel(const PtSphere *spheres, const PtMaterial *materials, uin
     if (err) return err;
     trace_t tr = { events, max_events, 0 };
     float rgba[4]; uint64_t paths = 0;
-    render_pixel(spheres, materials, n, scene, camera, gs, px, py, rgba, &paths, &tr, NULL, NULL, NULL);
+    int has_alpha = 0;
+    for (uint32_t i = 0; i < n && !has_alpha; i++) has_alpha = materials[i].AlphaMode != PT_ALPHA_OPAQUE;
+    render_pixel(spheres, materials, n, scene, camera, gs, px, py, rgba, &paths, &tr, NULL, NULL, NULL, has_alpha);
     *n_events = tr.n_events;
     return 0;
 }

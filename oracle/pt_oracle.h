@@ -52,6 +52,9 @@ int oracle_render_textured(const PtSphere *spheres, const PtMaterial *materials,
 int oracle_closest_hit(const PtSphere *spheres, uint32_t n, const float o[3], const float d[3], float tmin, float tmax, int use_bvh,
                        void **bvh_cache, float *t, uint32_t *id);
 void oracle_free_bvh(void *bvh);
+/* ... with alpha-tested hits (spec S10; RaytracingHelpers.hlsli:19-43, ShadingHelpers.hlsli:105-115): brute force, textures may be NULL */
+int oracle_closest_hit_alpha(const PtSphere *spheres, const PtMaterial *materials, uint32_t n, const OracleTextures *textures,
+                             const float o[3], const float d[3], float tmin, float tmax, float *t, uint32_t *id);
 /* leaf of row N4: uniform direction in the cone the sphere (C, r) subtends from P; returns 0 when P is inside the sphere */
 int oracle_sample_sphere_cone(const float P[3], const float C[3], float r, float u1, float u2, float L[3], float *inv_pdf);
 /* leaves of row N1 */

@@ -192,11 +192,37 @@ def hit_sphere(o, d, tmin, tmax, c, r):
     return t if (t > tmin and t < tmax) else None
 
 
-def cast_ray(spheres, o, d, tmin, tmax):
-    """closest hit, ties to the lowest id (ascending scan, strict <); returns the HitInfo the loop needs or None"""
+def surface_crossings(o, d, c, r):
+    """both parameters at which the line meets the sphere, ascending (the textbook quadratic, unit d), or () -- the candidates
+    of a non-opaque object, which the reference meets as the front and the back triangles of its mesh"""
+    f = sub(o, c)
+    b = dot(f, d)
+    disc = b * b - (dot(f, f) - r * r)
+    if not (disc >= 0.0):
+        return ()
+    sq = math.sqrt(disc)
+    return (-b - sq, -b + sq)
+
+
+def is_opaque(mat):
+    """IsOpaque (ShadingHelpers.hlsli:105-115) without a base-colour map: BaseColor.a >= AlphaCutoff"""
+    return mat["BaseColor"][3] >= mat["AlphaCutoff"]
+
+
+def cast_ray(spheres, o, d, tmin, tmax, materials=None):
+    """closest hit, ties to the lowest id (ascending scan, strict <); returns the HitInfo the loop needs or None.
+    An object whose AlphaMode is not Opaque is non-opaque geometry (Scene.ixx:242-243): each of its candidates is committed only
+    if IsOpaque accepts it (RaytracingHelpers.hlsli:19-43)."""
     best, best_id = tmax, MISS
     for i, (cx, cy, cz, r) in enumerate(spheres):
-        t = hit_sphere(o, d, tmin, math.inf, (cx, cy, cz), r)
+        if materials is not None and materials[i].get("AlphaMode", 0) != 0:
+            t = None
+            for candidate in surface_crossings(o, d, (cx, cy, cz), r):   # the nearer candidate first
+                if candidate > tmin and is_opaque(materials[i]):
+                    t = candidate
+                    break
+        else:
+            t = hit_sphere(o, d, tmin, math.inf, (cx, cy, cz), r)
         if t is not None and t < best:
             best, best_id = t, i
     if best_id == MISS:
@@ -330,7 +356,7 @@ def trace_pixel(spheres, materials, env_color, cam, w, h, frame, bounces, spp, r
     inv_cos = 1.0 / dot(unit(cam["Forward"]), d0)
     o0 = tuple(cam["Position"])
     events = []
-    primary = cast_ray(spheres, o0, d0, cam["Near"] * inv_cos, cam["Far"] * inv_cos)
+    primary = cast_ray(spheres, o0, d0, cam["Near"] * inv_cos, cam["Far"] * inv_cos, materials)
     if primary is None:                                           # GBufferGeneration.hlsl:223-227; Raytracing.hlsl:249-252
         events.append({"sample": 0, "bounce": 0, "id": MISS, "t": math.inf, "L": (0, 0, 0), "T": (1, 1, 1), "rng": rng.state, "lobe": -1, "flag": 1})
         return environment(env_color, d0), events
@@ -341,7 +367,7 @@ def trace_pixel(spheres, materials, env_color, cam, w, h, frame, bounces, spp, r
         for bounce in range(bounces + 1):                         # :213
             if bounce:
                 o, d = safe_origin(hit, L), L                     # :219-224
-                hit = cast_ray(spheres, o, d, 0.0, math.inf)
+                hit = cast_ray(spheres, o, d, 0.0, math.inf, materials)
             ev = {"sample": s, "bounce": bounce, "id": MISS if hit is None else hit["id"], "t": math.inf if hit is None else hit["t"], "lobe": lobe}
             if hit is None:                                       # :242-259
                 sample_radiance = add(sample_radiance, mul(T, environment(env_color, d)))

@@ -20,19 +20,26 @@ CASES = {
     "c2_heroes": ("demo", 1920, 1080, 8, 1, True, 0, [(x, y) for y in range(470, 560, 9) for x in range(800, 1130, 13)]),
     "c2_deep_norr": ("demo", 1920, 1080, 24, 1, False, 3, [(x, y) for y in range(440, 600, 31) for x in range(880, 1060, 23)]),
     "c2_spp4": ("demo", 1920, 1080, 8, 4, True, 5, [(x, y) for y in range(500, 620, 29) for x in range(700, 1300, 61)]),
+    # alpha-tested hits (spec S10): masked-away and kept spheres among the heroes
+    "c1_alpha": ("small_alpha", 256, 256, 4, 2, True, 1, [(x, y) for y in range(84, 140, 5) for x in range(96, 162, 5)]),
 }
 EVENT_COLS = 16  # sample, bounce, id, t, L(3), T(3), rng, lobe, flag, radiance(3) [radiance on the pixel's last row]
 
 
 def _scene(dxrs, host, kind):
-    spheres, materials, sd = host.scene(dxrs.host.SCENE_SMALL if kind == "small" else dxrs.host.SCENE_DEMO, seed=0)
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_SMALL if kind.startswith("small") else dxrs.host.SCENE_DEMO, seed=0)
+    if kind == "small_alpha":  # alpha-tested hits (spec S10): the bronze hero and the big sphere are masked away, the glass hero is Blend and stays
+        materials["AlphaMode"][[1, 3, 14]] = (2, 1, 1)
+        materials["BaseColor"][[1, 3, 14], 3] = (0.8, 0.25, 0.4)
+        materials["AlphaCutoff"][14] = 0.45
     return spheres, materials, sd
 
 
 def _python_scene(spheres, materials, sd, cam):
     sph = [(float(s["cx"]), float(s["cy"]), float(s["cz"]), float(s["r"])) for s in spheres]
     mats = [{"BaseColor": [float(v) for v in m["BaseColor"]], "EmissiveStrength": float(m["EmissiveStrength"]), "EmissiveColor": [float(v) for v in m["EmissiveColor"]],
-             "Metallic": float(m["Metallic"]), "Roughness": float(m["Roughness"]), "IOR": float(m["IOR"]), "Transmission": float(m["Transmission"])} for m in materials]
+             "Metallic": float(m["Metallic"]), "Roughness": float(m["Roughness"]), "IOR": float(m["IOR"]), "Transmission": float(m["Transmission"]),
+             "AlphaMode": int(m["AlphaMode"]), "AlphaCutoff": float(m["AlphaCutoff"])} for m in materials]
     env = [float(v) for v in sd.EnvironmentLightColor]
     c = {"Position": tuple(cam.Position), "Right": tuple(cam.RightDirection), "Up": tuple(cam.UpDirection), "Forward": tuple(cam.ForwardDirection),
          "Near": float(cam.NearDepth), "Far": float(cam.FarDepth), "Jitter": tuple(cam.Jitter)}
