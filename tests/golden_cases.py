@@ -63,6 +63,19 @@ def cases(dxrs, host):
             sdc.EnvironmentLightTransform[4 * r + k] = float(rot[r][k])
     out.append(dict(file="a18_cube_env_crop_64_64_96x96.npy", spheres=s, materials=m, sd=sdc, cam=host.camera(256, 256, jitter_index=2),
                     gs=t.graphics_settings(256, 256, frame_index=2, bounces=5, spp=1), rect=(64, 64, 96, 96), textures=tc))
+    # row a5, alpha-tested hits (spec S10): the small scene seen from close by; the bronze hero is masked away as a whole, the big sphere
+    # shows holes where its base-colour map's alpha falls below the cutoff (its far side is seen through them), the glass hero is Blend and stays
+    sa, ma = s.copy(), m.copy()
+    ma["AlphaMode"][[1, 3, 14]] = (2, 1, 1)
+    ma["BaseColor"][[1, 3, 14], 3] = (0.8, 0.25, 1.0)
+    ta = T.TextureSet(len(sa))
+    holes = np.full((32, 64, 4), 255, np.uint8)
+    holes[..., :3] = T.planet_albedo(64, 32, 7)
+    holes[..., 3] = np.where(T.value_noise(64, 32, 8) > 0.5, 255, 40)
+    ta.assign(14, t.TEXTURE_MAP_BASE_COLOR, ta.add_image(holes, srgb=True))
+    ta.set_rotation(14, T.quaternion_axis_angle((0.2, 1.0, 0.1), 0.7))
+    out.append(dict(file="a5_alpha_crop_48_8_160x120.npy", spheres=sa, materials=ma, sd=sd, cam=host.camera(256, 192, position=(0.0, 2.0, -7.0), jitter_index=1),
+                    gs=t.graphics_settings(256, 192, frame_index=1, bounces=5, spp=2), rect=(48, 8, 160, 120), textures=ta))
     return out
 
 
