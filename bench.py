@@ -52,8 +52,12 @@ def main():
                     help="tiled path: shares of the frame rank 0 renders (every other rank renders one; 0 = rank 0 renders everything); "
                          "-1 = measure a few candidates before the warm-up and keep the fastest")
     ap.add_argument("--gather-batch", type=int, default=0, help="tiled path: frames per RCCL gather (0 = frames in flight)")
-    ap.add_argument("--gather", choices=["cabi", "torch"], default="cabi",
-                    help="tiled path, N > 1: the exchange through the C-ABI's pt_gather (default; falls back to torch if its self-check fails) or torch.distributed.gather")
+    ap.add_argument("--gather", choices=["cabi", "torch"], default="torch",
+                    help="tiled path, N > 1: torch.distributed.gather (default) or the C-ABI's pt_gather (falls back to torch if its self-check fails). "
+                         "With the default the C-ABI exchange is still checked and timed AFTER the measurement, under a watchdog (result: config.tile_exchange.cabi_check)")
+    ap.add_argument("--moving-camera", action="store_true",
+                    help="the camera pose changes every frame (a slow orbit, as App::Update's camera block moves it: Source/App.cpp:531-553), so nothing a resting view "
+                         "lets the renderer cache (primary-beam lists) applies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="the CPU baseline renders every n-th row of each frame")
@@ -130,17 +134,23 @@ def main():
     gs = graphics_settings(w, h, frame_index=0, bounces=args.bounces, spp=args.spp, di=args.di)
     r.set_constants(gs)
     cams = [host.camera(w, h, jitter_index=k, jitter_count=8) for k in range(8)]
+    if args.moving_camera:
+        import math
+        n_cam = 3 * args.steps + args.warmup + 64
+        cams = [host.camera(w, h, position=(0.6 * math.sin(0.01 * k), 0.05 * math.sin(0.013 * k), -15.0 + 0.4 * math.cos(0.01 * k)), jitter_index=k % 8, jitter_count=8)
+                for k in range(n_cam)]
 
     def set_frame(k, rr=None):
         rr = rr or r
         gs.FrameIndex = k
         if args.animate:
             rr.update_spheres(anim[k])  # upload + LBVH refit on this frame's stream (Scene::Refresh + TLAS rebuild analogue)
-        rr.set_camera(cams[k % 8])
+        rr.set_camera(cams[k % len(cams)])
         rr.set_constants(gs)
 
     # multi-buffered outputs: frame k writes buffer k % frames_in_flight (the reference's swap chain, generalised)
     tune_log = {}
+    cabi, ops, ex = False, None, None
     if not tiled:
         frames = [torch.empty((h * w, 4), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     else:
@@ -150,13 +160,12 @@ def main():
         batch = max(args.gather_batch or nbuf, nbuf - 1, 1)
         # The exchange itself: the C-ABI's pt_gather (RCCL grouped send/recv behind include/pt_api.h -- what a C++ host uses),
         # verified on the live job with a known pattern before it is trusted; torch.distributed.gather otherwise.
-        cabi = False
         if args.gather == "cabi" and world > 1 and not rehearsal:
             cabi = init_cabi_gather(r, dist, torch, dev, rank, world)
         ops = HipOps(r, dev, set_frame, cabi_gather=cabi)
         if rehearsal and world > 1:
             ops.gather_parts = lambda send, recv, nbytes: staged_gather(torch, dist, rank, world, send, recv, nbytes)
-        ex = TileExchange(ops, w, h, rank, world, batch, rehearse=args.force_tiles and world == 1)
+        ex = TileExchange(ops, w, h, rank, world, batch, rehearse=args.force_tiles and world == 1, frames_in_flight=nbuf)
         gather_kind = ("gloo, staged through the host (PT_BENCH_REHEARSAL: all ranks on one GPU, timings meaningless)" if rehearsal else
                        "pt_gather (C-ABI, RCCL send/recv)" if cabi else "torch.distributed.gather (RCCL)")
     if args.animate:
@@ -205,8 +214,9 @@ def main():
             ex.configure(args.root_weight)
         else:
             # untimed, before the warm-up: try a few root weights on the live job and keep the fastest
-            n_tune = 6 * ex.batch
-            ex.autotune(lambda e: run_steps(0, n_tune), sync_all, log=tune_log)
+            # (five candidates x two runs of two batches: a few dozen frames, small against the measurement itself)
+            n_tune = 2 * ex.batch
+            ex.autotune(lambda e: run_steps(0, n_tune), sync_all, candidates=[1, 2, 4, 8, 0], log=tune_log)
     run_steps(0, args.warmup)
     r.totals(reset=True)
     elapsed = run_steps(args.warmup, args.steps)
@@ -223,6 +233,23 @@ def main():
         r.set_profiling(False)
         tot_ev = r.totals(reset=True)
     rays, paths = int(tot.rays), int(tot.paths)
+    # The reference's own frame contract: one frame at a time -- Tick -> Render -> WaitForGPU (Source/App.cpp:144-186).  `value` above is
+    # the throughput of frames in flight (its swap chain, generalised); this is the latency of a frame the caller waits for.
+    serial = None
+    if not tiled:
+        k0 = args.warmup + 2 * args.steps
+        lat = []
+        for k in range(24):
+            set_frame(k0 + k)
+            torch.cuda.synchronize(dev)
+            t0s = time.perf_counter()
+            r.render_device(frames[k % nbuf].data_ptr())
+            torch.cuda.synchronize(dev)
+            lat.append(time.perf_counter() - t0s)
+        lat = sorted(lat[4:])
+        serial = {"ms_per_frame": sum(lat) / len(lat) * 1e3, "median_ms": lat[len(lat) // 2] * 1e3, "min_ms": lat[0] * 1e3, "frames": len(lat),
+                  "contract": "one frame at a time: submit, then wait for the GPU (App::Tick -> Render -> WaitForGPU, Source/App.cpp:144-186); host submit + sync included"}
+        r.totals(reset=True)
     if tiled:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -230,6 +257,11 @@ def main():
         c = torch.tensor([rays, paths], dtype=torch.int64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         rays, paths = int(c[0].item()), int(c[1].item())
+        # what every rank did, as seen by rank 0: a rank that rendered nothing, or a world that is not the one asked for, shows here
+        mine = torch.tensor([int(tot.rays), int(tot.pixels)], dtype=torch.int64, device=dev)
+        per_rank = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        per_rank = [[int(v) for v in t_.tolist()] for t_ in per_rank]
 
     result = None
     if rank == 0:
@@ -244,6 +276,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "latency_ms_one_frame": serial["ms_per_frame"] if serial else None,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -255,13 +288,20 @@ def main():
                             + (", sphere-light direct illumination (IsDIEnabled)" if args.di else "")
                             + (f", 32x32 tiles interleaved over {world} GPU(s) + RCCL gather to rank 0" if tiled else ""),
                 **({"tile_exchange": {"gather": gather_kind, "root_weight": ex.root_weight, "frames_per_gather": ex.batch, "root_tiles": ex.n_root,
-                                      "tiles_per_other_rank": ex.n_other, "autotune": tune_log or None}} if tiled else {}),
+                                      "tiles_per_other_rank": ex.n_other, "autotune": tune_log or None,
+                                      "ranks_seen": world, "rays_and_pixels_per_rank": per_rank}} if tiled else {}),
                 **({"rehearsal": "PT_BENCH_REHEARSAL=1: all ranks on ONE GPU over gloo -- control-flow rehearsal, not a measurement"} if rehearsal else {}),
                 "frames_in_flight": args.frames_in_flight,
+                "one_frame_at_a_time": serial,
                 "animated": bool(args.animate),
+                "moving_camera": bool(args.moving_camera),
+                # the primary pass of a RESTING view takes its candidates from cached per-block sphere lists (DESIGN.md "Primary beams"); a moving
+                # camera or an animated scene traverses per ray -- run with --moving-camera / --animate for those figures
+                "primary_beams": {"frames_using_cached_lists": int(tot.beams_used), "of": args.steps},
                 "rays_per_frame": rays / args.steps,
-                "lbvh": {"nodes": int(accel.node_count), "depth": int(accel.depth), "lds_resident": bool(accel.lds_resident), "build_ms": float(accel.build_ms),
-                         "first_build_ms": first_build_ms},
+                "accel": {"builder": {0: "device LBVH (Morton order, Karras)", 1: "host LBVH", 2: "host SAH topology (scenes up to 4096 spheres) + device boxes"}.get(int(accel.builder), str(int(accel.builder))),
+                          "built": "before the timed region; --animate refits it inside", "nodes": int(accel.node_count), "depth": int(accel.depth),
+                          "lds_resident": bool(accel.lds_resident), "build_ms": float(accel.build_ms), "first_build_ms": first_build_ms},
             },
         }
 
@@ -281,13 +321,13 @@ def main():
         while o_frames < 64 and o_time * cores < 15.0:
             gs.FrameIndex = args.warmup + o_frames
             t0c = time.perf_counter()
-            _, ost = oracle.render(spheres, materials, sd, cams[(args.warmup + o_frames) % 8], gs, row_step=args.cpu_row_step, threads=cores, textures=tex)
+            _, ost = oracle.render(spheres, materials, sd, cams[(args.warmup + o_frames) % len(cams)], gs, row_step=args.cpu_row_step, threads=cores, textures=tex)
             o_time += time.perf_counter() - t0c
             o_rays += int(ost.rays)
             o_frames += 1
         # single-thread figure: every 16th row of one frame
         t0c = time.perf_counter()
-        _, ost1 = oracle.render(spheres, materials, sd, cams[args.warmup % 8], gs, row_step=16, threads=1, textures=tex)
+        _, ost1 = oracle.render(spheres, materials, sd, cams[args.warmup % len(cams)], gs, row_step=16, threads=1, textures=tex)
         t_single = time.perf_counter() - t0c
         result["cpu_baseline"] = {
             "value": o_rays / o_time / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
@@ -301,9 +341,65 @@ def main():
 
     if rank == 0:
         os.write(_RESULT_FD, (json.dumps(result) + "\n").encode())  # the ONE line of this job's stdout
+    # The C-ABI's own exchange (pt_comm_init / pt_gather) has never met more than one GPU before the first multi-GPU run of this
+    # script, so the measurement above went through torch.distributed.gather.  With the result line safely out, pt_gather is now
+    # brought up, checked bit for bit against the frames of the torch path and timed -- under a watchdog, so that a rank stuck in
+    # ncclCommInitRank ends the job instead of hanging it.  Outcome: one tagged line on stderr (+ gpurun_out/cabi_check_<N>gpus.json).
+    if tiled and world > 1 and not rehearsal and not cabi:
+        cabi_post_check(r, ex, ops, dist, torch, dev, rank, world, run_steps, args)
     r.close()
     if tiled:
         dist.destroy_process_group()
+
+
+def cabi_post_check(r, ex, ops, dist, torch, dev, rank, world, run_steps, args):
+    import threading
+
+    def give_up():
+        if rank == 0:
+            print('[bench] cabi_check: {"ok": false, "reason": "timed out after 60 s (a rank did not come back from pt_comm_init / pt_gather)"}', file=sys.stderr, flush=True)
+        os._exit(0)  # the result line is already out; a hung collective cannot be unwound
+
+    dog = threading.Timer(60.0, give_up)
+    dog.daemon = True
+    dog.start()
+    out = {"ok": False}
+    try:
+        def batch_frames(first):
+            for k in range(ex.batch):
+                ex.submit(first + k)
+            ex.finish()
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            return [f.clone() for f in ex.frames[: ex.batch]] if rank == 0 else None
+
+        first = args.warmup + 3 * args.steps + 64
+        ref = batch_frames(first)
+        t_torch = run_steps(first, 2 * ex.batch) / (2 * ex.batch)
+        if init_cabi_gather(r, dist, torch, dev, rank, world):
+            ops.gather_parts = ops._gather_parts
+            got = batch_frames(first)
+            same = 1
+            if rank == 0:
+                same = int(all(torch.equal(a, b) for a, b in zip(ref, got)))
+            flag = torch.tensor([same], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            t_cabi = run_steps(first, 2 * ex.batch) / (2 * ex.batch)
+            out = {"ok": bool(int(flag.item())), "frames_bit_identical_to_torch_gather": bool(int(flag.item())),
+                   "ms_per_step_pt_gather": t_cabi * 1e3, "ms_per_step_torch_gather": t_torch * 1e3, "frames_compared": ex.batch}
+        else:
+            out = {"ok": False, "reason": "pt_comm_init or its self-check failed on some rank (see stderr)"}
+    except Exception as e:  # noqa: BLE001
+        out = {"ok": False, "reason": f"{type(e).__name__}: {e}"}
+    dog.cancel()
+    if rank == 0:
+        print("[bench] cabi_check: " + json.dumps(out), file=sys.stderr, flush=True)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", f"cabi_check_{world}gpus.json"), "w") as f:
+                json.dump(out, f)
+        except OSError:
+            pass
 
 
 def load_counters(workload):
@@ -353,12 +449,17 @@ def roofline_object(args, w, h, world, tiled, prof, tot_ev, qs, elapsed, elapsed
     workload = f"{args.scene}-{w}x{h}-{args.spp}spp-{args.bounces}b"
     plain = not (args.di or args.textures or args.env_map or args.animate or tiled)
     counters, stale = load_counters(workload) if plain else (None, "counters are collected for the plain single-GPU workloads only")
-    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    # `bound` / `achieved` / `frac` are the measurement contract's HBM figures in SURVEY 8(d)'s NOTIONAL bytes; `binding` names what the
+    # kernels are really limited by (VALU issue: see `valu` and `traffic`)
+    out = {"bound": "hbm", "binding": "valu", "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     if split:
         # split schedule (BVH in global memory): every ray is traced by a traversal-type launch (primary_kernel, traverse[_dyn]_kernel,
         # tail_kernel); the class is all of them
         name, cls = "traversal kernels of the split schedule (primary_kernel + traverse_dyn_kernel + tail_kernel)", ("primary", "traverse", "tail")
+        # SURVEY 8(d) prices a node visit at 32 B (a box-in-own-node record); the records this build reads are 64 B (two child boxes:
+        # one fetch tests both children).  `frac` uses the bytes really read; `frac_survey_32B_nodes` is the contract's literal figure.
         scene_bytes = 64.0 * tot_ev.node_visits + 16.0 * tot_ev.sphere_tests
+        scene_bytes_32 = 32.0 * tot_ev.node_visits + 16.0 * tot_ev.sphere_tests
         b = (160.0 * my_rays + 40.0 * tot_ev.paths / n_f) * n_f + scene_bytes
         ms, n = prof.ms_traverse + prof.ms_tail, prof.traverse_launches + prof.tail_launches
         out["scene_term"] = {"node_visits_per_ray": tot_ev.node_visits / max(tot_ev.rays, 1), "sphere_tests_per_ray": tot_ev.sphere_tests / max(tot_ev.rays, 1),
@@ -384,6 +485,8 @@ def roofline_object(args, w, h, world, tiled, prof, tot_ev, qs, elapsed, elapsed
             b, ms, n, rays_class = (160.0 * rays_loop + 40.0 * loop_in * args.spp) * n_f, prof.ms_tail, prof.tail_launches, rays_loop
             impl = (48.0 * loop_in + 16.0 * loop_in) * n_f
     achieved = (b / n) / (ms / n * 1e-3) / 1e9 if n and ms > 0 else 0.0
+    if split and n and ms > 0:
+        out["frac_survey_32B_nodes"] = ((b - scene_bytes + scene_bytes_32) / n) / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS
     out.update(kernel=name, achieved=achieved, frac=achieved / HBM_PEAK_GBS, bytes_per_launch=b / max(n, 1), avg_launch_ms=ms / max(n, 1), launches_per_frame=n / n_f,
                rays_per_launch=rays_class / max(n / n_f, 1),
                accounting="SURVEY 8(d): 160 B per ray traced + 40 B per path finished by these launches" + (" + the scene term" if split else ""))
@@ -452,10 +555,23 @@ def init_cabi_gather(r, dist, torch, dev, rank, world):
     if int(flag.item()) == 0:
         return False
     ok = 1
+    ids = [my_id if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
     try:
-        ids = [my_id if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
         r.comm_init(ids[0], rank, world)
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] rank {rank}: pt_comm_init failed ({e}); using torch.distributed.gather", file=sys.stderr)
+        ok = 0
+    # "communicator up" is agreed on BEFORE the first pt_gather: a rank whose pt_comm_init failed must not leave the others in the receive group
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        try:
+            r.comm_destroy()
+        except Exception:  # noqa: BLE001
+            pass
+        return False
+    try:
         n = 4096
         send = torch.full((n,), float(rank), dtype=torch.float32, device=dev)
         recv = torch.zeros((max(world - 1, 1), n), dtype=torch.float32, device=dev)

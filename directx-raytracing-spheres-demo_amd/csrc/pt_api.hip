@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library itself is loaded at run time (pt_comm_init)
 #include <dlfcn.h>
+#include <link.h>
 
 #include <algorithm>
 #include <chrono>
@@ -72,7 +73,8 @@ struct Lane {
     float4* d_nodes = nullptr;
     uint32_t* d_refit_flags = nullptr;
     uint32_t* d_refit_hdr = nullptr;
-    PtSphere* h_stage = nullptr;      // pinned upload staging
+    PtSphere* h_stage = nullptr;      // pinned upload staging, host-mapped ...
+    const float4* d_stage = nullptr;  // ... and its device address (the single-launch refit of small scenes reads the staging buffer itself)
     hipEvent_t ev_upload = nullptr;   // the last upload from h_stage has been consumed
     hipEvent_t ev_poll[4] = {};       // queue-size read-backs of the last passes (spp > 1 lagged polling)
     uint32_t scene_n = 0;             // sphere count the private copy was allocated for
@@ -163,6 +165,7 @@ struct PtContext {
     float4* d_out = nullptr;
     size_t cap_out = 0;
     uint64_t tot_pixels = 0, tot_paths = 0, tot_fixed_bytes = 0, tot_sec_coeff = 96;  // host-known parts of the totals
+    uint32_t tot_beam_frames = 0;  // frames since the last reset whose primary pass used the primary-beam lists
 
     // Primary beams (DESIGN.md "Primary beams"): per-8x8-block candidate sphere lists for the primary pass.  They depend on the
     // camera pose, the frame geometry and the scene -- not on the frame index or the jitter (the beams are a pixel wider than
@@ -249,9 +252,17 @@ Rccl& rccl()
 {
     static Rccl r;
     if (r.handle || !r.error.empty()) return r;
+    // A process that already carries an RCCL (PyTorch bundles its own copy, under its own path) must not get a second one: look through
+    // the objects that are mapped for a librccl and take a handle to THAT one (RTLD_NOLOAD); only a process without any loads the system's.
+    std::string mapped;
+    dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* data) {
+        if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl")) { *static_cast<std::string*>(data) = info->dlpi_name; return 1; }
+        return 0;
+    }, &mapped);
+    if (!mapped.empty()) r.handle = dlopen(mapped.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
     for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
-        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (r.handle) break;
+        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     }
     if (!r.handle) { r.error = std::string("cannot load librccl.so: ") + dlerror(); return r; }
     auto sym = [&](const char* n) { void* p = dlsym(r.handle, n); if (!p && r.error.empty()) r.error = std::string("librccl.so lacks ") + n; return p; };
@@ -291,7 +302,7 @@ void free_dev(T*& p)
 void free_lane_scene(Lane& L)
 {
     free_dev(L.d_sph); free_dev(L.d_sph_sorted); free_dev(L.d_nodes); free_dev(L.d_refit_flags); free_dev(L.d_refit_hdr);
-    if (L.h_stage) { (void)hipHostFree(L.h_stage); L.h_stage = nullptr; }
+    if (L.h_stage) { (void)hipHostFree(L.h_stage); L.h_stage = nullptr; L.d_stage = nullptr; }
     L.scene_n = 0;
     L.scene_private = false;
     L.upload_pending = false;
@@ -630,7 +641,8 @@ static PtStatus stage_spheres_on_lane(PtContext* c, Lane& L, const PtSphere* sph
         PT_HIP(c, hipMalloc(&L.d_nodes, (size_t)std::max(1u, n - 1) * sizeof(PtBvhNode)));
         PT_HIP(c, hipMalloc(&L.d_refit_flags, (size_t)n * sizeof(uint32_t)));
         PT_HIP(c, hipMalloc(&L.d_refit_hdr, 16 * sizeof(uint32_t)));
-        PT_HIP(c, hipHostMalloc(&L.h_stage, (size_t)n * sizeof(PtSphere)));
+        PT_HIP(c, hipHostMalloc(&L.h_stage, (size_t)n * sizeof(PtSphere), hipHostMallocMapped));
+        { void* dp = nullptr; PT_HIP(c, hipHostGetDevicePointer(&dp, L.h_stage, 0)); L.d_stage = static_cast<const float4*>(dp); }
         if (!L.ev_upload) PT_HIP(c, hipEventCreateWithFlags(&L.ev_upload, hipEventDisableTiming));
         L.scene_n = n;
     }
@@ -657,7 +669,7 @@ static PtStatus refit_lane(PtContext* c, Lane& L)
     L.needs_refit = false;
     if (L.upload_pending) {
         L.upload_pending = false;
-        PT_HIP(c, lbvh_gpu_refit_fused(c->gpu_builder, reinterpret_cast<const float4*>(L.h_stage), L.d_sph, c->n, reinterpret_cast<PtBvhNode*>(L.d_nodes), L.d_sph_sorted,
+        PT_HIP(c, lbvh_gpu_refit_fused(c->gpu_builder, L.d_stage, L.d_sph, c->n, reinterpret_cast<PtBvhNode*>(L.d_nodes), L.d_sph_sorted,
                                        c->d_sorted_id, L.d_refit_hdr, L.stream));
         PT_HIP(c, hipEventRecord(L.ev_upload, L.stream));  // the staging buffer has been read once this kernel is done
         return PT_OK;
@@ -948,6 +960,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     c->tot_paths += valid_pixels * spp;
     c->tot_fixed_bytes += fixed_bytes(split, pm.n_slots, valid_pixels, spp > 1 ? valid_pixels * spp : 0);
     c->tot_sec_coeff = bytes_per_secondary(split);
+    if (beam_lists) c->tot_beam_frames++;
     if (timed) {
         PT_HIP(c, hipEventRecord(c->ev1, L.stream));
         if (c->knobs.debug_counts >= 0) {
@@ -1722,7 +1735,8 @@ PtStatus pt_get_totals(PtContext* c, PtStats* totals, int reset)
     totals->paths = c->tot_paths;
     totals->pixels = c->tot_pixels;
     totals->bytes_algorithmic = c->tot_sec_coeff * secondary + c->tot_fixed_bytes;
-    if (reset) c->tot_pixels = c->tot_paths = c->tot_fixed_bytes = 0;
+    totals->beams_used = c->tot_beam_frames;
+    if (reset) { c->tot_pixels = c->tot_paths = c->tot_fixed_bytes = 0; c->tot_beam_frames = 0; }
     return PT_OK;
 }
 

@@ -36,7 +36,12 @@ from . import tiles
 
 
 class TileExchange:
-    def __init__(self, ops, w, h, rank, world, batch, ts=32, rehearse=False, rgb=True):
+    def __init__(self, ops, w, h, rank, world, batch, ts=32, rehearse=False, rgb=True, frames_in_flight=1):
+        """frames_in_flight: that of the renderer behind `ops`.  The two batch buffers alternate and a frame only waits for the consumer
+        of its buffer from frames_in_flight - 1 calls back (pt_api.hip render_common), so a shorter batch would let a frame overwrite
+        tiles that the previous batch's gather / un-swizzle has not read yet: refused."""
+        if frames_in_flight > 1 and max(1, batch) < frames_in_flight - 1:
+            raise ValueError(f"TileExchange: batch {batch} is shorter than frames in flight - 1 ({frames_in_flight - 1})")
         self.ops, self.w, self.h, self.rank, self.world, self.batch, self.ts = ops, w, h, rank, world, max(1, batch), ts
         self.rgb = rgb  # exchange buffers carry 3 floats per pixel
         self.rehearse = rehearse  # world == 1: still issue the collective (with nothing to receive) to rehearse the call path

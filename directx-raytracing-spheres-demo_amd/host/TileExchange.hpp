@@ -85,10 +85,14 @@ private:
 template <class Backend>
 class TileExchange {
 public:
-    TileExchange(Backend& backend, uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t batch, bool rgb = true, uint32_t ts = 32)
+    // framesInFlight: PtConfig::frames_in_flight of the context that renders (0 / 1 = one).  The two batch buffers alternate, and a frame
+    // only waits for the consumer of ITS buffer from framesInFlight - 1 calls back (pt_api.hip render_common): a batch shorter than
+    // that would let a frame overwrite tiles the gather / un-swizzle of the previous batch has not read yet -- refused here.
+    TileExchange(Backend& backend, uint32_t w, uint32_t h, uint32_t rank, uint32_t world, uint32_t batch, bool rgb = true, uint32_t ts = 32, uint32_t framesInFlight = 1)
         : m_b(backend), m_w(w), m_h(h), m_rank(rank), m_world(world), m_batch(batch ? batch : 1), m_ts(ts), m_rgb(rgb), m_tilePx(uint64_t(ts) * ts)
     {
         if (world == 0 || rank >= world) throw std::invalid_argument("TileExchange: need rank < world");
+        if (framesInFlight > 1 && m_batch + 1 < framesInFlight) throw std::invalid_argument("TileExchange: batch must be at least frames in flight - 1");
         // buffers sized for the largest share any root weight can give this rank
         const uint64_t capRoot = tiles::TileCount(w, h, ts);
         m_capOther = world > 1 ? tiles::RangeTileCount(w, h, tiles::Range{ 1, 1, world }, ts) : 0;

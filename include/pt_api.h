@@ -101,7 +101,8 @@ typedef struct PtStats {
     uint64_t bytes_algorithmic; /* DESIGN.md byte model: per-ray queue traffic + per-path accumulate/store */
     double ms_tail;             /* device time of the fused tail launch (0 unless profiling on) */
     uint32_t tail_launches;
-    uint32_t beams_used;        /* 1: the primary pass took its candidates from the primary-beam lists of a resting view */
+    uint32_t beams_used;        /* pt_render*: 1 = the primary pass took its candidates from the primary-beam lists of a resting view;
+                                   pt_get_totals: the number of such frames since the last reset */
     uint64_t rays_first_pass_inline; /* pt_get_totals only: secondary rays the primary passes traced in registers (the first
                                         bounce of a 1-spp frame never enters a queue); part of `rays` */
     uint64_t node_visits;       /* pt_get_totals only, scenes traversed in global memory: BVH node records read and ... */
@@ -196,8 +197,10 @@ PtStatus pt_unpack_tiles_rgb(PtContext *ctx, const void *packed_device, uint64_t
  * The table is also where SceneData.EnvironmentLightTextureDescriptor points (row a18's texture branch,
  * ShadingHelpers.hlsli:13-24: a lat-long map, or the first of the six faces of a cube map; usually PT_TEXTURE_RGBA32_FLOAT);
  * pt_render* fails with PT_ERR_STATE while the scene names an environment texture the table does not hold.
- * pt_update_rotations replaces the quaternions (Earth's spin, the Moon's tidal lock: Source/MyScene.ixx:240-291); it
- * waits for the frames in flight. */
+ * pt_update_rotations replaces the quaternions (Earth's spin, the Moon's tidal lock: Source/MyScene.ixx:240-291).  It does no
+ * device work and does not wait: the frames in flight keep the rotations they were submitted with, every later render call
+ * uploads the new ones into its lane's own copy on its own stream.  A base-colour map on a sphere whose AlphaMode is not
+ * Opaque makes its alpha test a per-crossing one (pt_set_scene). */
 PtStatus pt_set_textures(PtContext *ctx, const PtTexture *textures, uint32_t n_textures,
                          const PtObjectTextures *object_textures, const float *rotations);
 PtStatus pt_update_rotations(PtContext *ctx, const float *rotations, uint32_t n);
