@@ -42,7 +42,7 @@ struct EventPair {
 struct Knobs {
     int split = -1, traverse_blocks_per_cu = -1, fused_threads = -1, no_adaptive_grid = -1, shade_blocks_per_cu = -1, tail_threshold = -1,
         tail_blocks_per_cu = -1, loop_threads = -1, inline2_min_slots = -1, tail_after = -1, seg = -1, loop_use_tail = -1, fuse_loop = -1,
-        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1, lane_priority = -1, fused_refit = -1;
+        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1, lane_priority = -1, fused_refit = -1, primary_cache = -1;
 };
 
 // Per-frame-in-flight state (see PtContext::lanes).
@@ -312,7 +312,7 @@ void free_lane_scene(Lane& L)
 void free_lane_buffers(Lane& L)
 {
     for (auto& q : L.q) { free_dev(q.q0); free_dev(q.q1); free_dev(q.q2); free_dev(q.hit); }
-    free_dev(L.scratch.sample_rad); free_dev(L.scratch.radiance); free_dev(L.scratch.primary_hit); free_dev(L.scratch.di);
+    free_dev(L.scratch.sample_rad); free_dev(L.scratch.radiance); free_dev(L.scratch.primary_hit); free_dev(L.scratch.di); free_dev(L.scratch.primary_cache);
     L.cap_slots = 0;
     L.scratch_spp = false;
 }
@@ -335,6 +335,7 @@ PtStatus ensure_buffers(PtContext* c, Lane& L, size_t n_slots, bool need_spp, bo
     if ((need_spp || need_di) && !L.scratch.primary_hit) PT_HIP(c, hipMalloc(&L.scratch.primary_hit, L.cap_slots * sizeof(uint2)));
     if (need_spp && !L.scratch_spp) {
         PT_HIP(c, hipMalloc(&L.scratch.radiance, L.cap_slots * sizeof(float4)));
+        PT_HIP(c, hipMalloc(&L.scratch.primary_cache, L.cap_slots * 3u * sizeof(float4)));  // Scratch::primary_cache: 48 B per slot
         L.scratch_spp = true;
     }
     if (n_counts > L.cap_counts) {
@@ -509,7 +510,7 @@ Knobs read_knobs()
     k.inline2_min_slots = env_knob("PT_INLINE2_MIN_SLOTS"); k.tail_after = env_knob("PT_TAIL_AFTER"); k.seg = env_knob("PT_SEG");
     k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.lane_priority = env_knob("PT_LANE_PRIORITY"); k.fused_refit = env_knob("PT_FUSED_REFIT"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
     k.dyn_blocks_per_cu = env_knob("PT_DYN_BLOCKS_PER_CU"); k.debug_counts = std::getenv("PT_DEBUG_COUNTS") ? 1 : -1; k.sah = env_knob("PT_SAH");
-    k.sah_max_spheres = env_knob("PT_SAH_MAX_SPHERES"); k.beams = env_knob("PT_BEAMS"); k.wide = env_knob("PT_WIDE"); k.descent = env_knob("PT_DESCENT"); k.roctx = env_knob("PT_ROCTX");
+    k.sah_max_spheres = env_knob("PT_SAH_MAX_SPHERES"); k.beams = env_knob("PT_BEAMS"); k.wide = env_knob("PT_WIDE"); k.descent = env_knob("PT_DESCENT"); k.roctx = env_knob("PT_ROCTX"); k.primary_cache = env_knob("PT_PRIMARY_CACHE");
     return k;
 }
 
@@ -892,6 +893,10 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
             // C3: 3.60 vs 3.69).  PT_FUSE_LOOP=0/1 overrides.
             const bool fuse = seg && knob_or(c->knobs.fuse_loop, pm.n_slots < 400000u ? 1u : 0u) != 0;
             if (seg) { fc_seg.seg_counts = L.d_seg_counts; fc_seg.n_segs = primary_grid; fc_seg.seg_cap = seg_cap; fc_seg.fuse_loop = fuse ? 1u : 0u; }
+            // spp > 1 with a separate looping pass over an untextured scene: the primary pass leaves each pixel's primary-hit record for the
+            // samples the looping pass regenerates (Scratch::primary_cache; PT_PRIMARY_CACHE=0 switches it off, for A/B runs)
+            Scratch scratch = L.scratch;
+            if (!(loop_is_main && !fuse && !sv.tex_maps && knob_or(c->knobs.primary_cache, 1u) != 0)) scratch.primary_cache = nullptr;
             // pass 0 generates + traces the primaries and shades them into queue 1; pass k >= 1 consumes queue k
             for (size_t k = 0;; k++) {
                 const RayQueue& qin = L.q[k & 1];
@@ -913,7 +918,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
                     break;
                 }
                 PT_HIP(c, bracket(loop ? 3 : (primary ? 0 : 1), [&] {
-                    return launch_bounce(sv, pm, fp, qin, qout, L.scratch, out, counts + k, counts + k + 1, k <= 1 ? fc_seg : fc, primary, loop, inline2, threads,
+                    return launch_bounce(sv, pm, fp, qin, qout, scratch, out, counts + k, counts + k + 1, k <= 1 ? fc_seg : fc, primary, loop, inline2, threads,
                                          primary ? primary_grid : grid_for(items, threads, cap), L.stream);
                 }));
                 if (loop || last_possible || (primary && fuse)) break;

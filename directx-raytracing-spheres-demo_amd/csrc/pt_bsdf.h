@@ -181,6 +181,56 @@ PT_HD f3 bsdf_eval(const Bsdf& b, const Surf& s, f3 L, f3 V, const float w[3], i
     return (F * k) * wr;
 }
 
+// EvaluatePDF(lobeType) followed by Evaluate(lobeType) of the lobe that was sampled (Raytracing.hlsl:335-345), with what the two share
+// computed once: the half vector (one normalisation instead of two), NoL, and for the specular lobe Vlocal and NoH.  Every value is
+// formed by the very operations of bsdf_pdf / bsdf_eval above, so pdf and f are bit-identical to theirs (tests/test_leaf_parity.py).
+// Returns false when pdf == 0 (the caller ends the sample, :336-339); f is then not evaluated.
+PT_HD bool bsdf_pdf_eval(const Bsdf& b, const Surf& s, f3 L, f3 V, const float w[3], int lobe, float& pdf, f3& f)
+{
+    const float wt = w[kLobeTransmission];
+    const float lw = w[lobe];
+    const f3 N = s.Ns;
+    const float nol = pt_abs(dot(N, L));
+    f = make_f3(0.0f, 0.0f, 0.0f);
+    if (lobe == kLobeTransmission) {
+        pdf = nol * lw;
+        if (pdf == 0.0f) return false;
+        f = (b.BaseColor * nol) * wt;
+        return true;
+    }
+    const bool front = dot(s.FrontNg, L) > 0.0f;
+    const float wr = 1.0f - wt;
+    if (lobe == kLobeDiffuse) {
+        pdf = front ? (nol * kInvPi) * lw : 0.0f * lw;
+        if (pdf == 0.0f) return false;
+        if (!front) { f = make_f3(0.0f, 0.0f, 0.0f) * wr; return true; }  // (pdf is NaN here: lw is not finite)
+        const f3 H = half_vector(b, s, L, V, wt > 0.0f);
+        const float nov = pt_abs(dot(N, V)), voh = pt_abs(dot(V, H));
+        const float dt = diffuse_term(b.Roughness, nol, nov, voh);
+        f = ((b.Albedo * nol) * dt) * wr;
+        return true;
+    }
+    // specular reflection
+    if (!front) {
+        pdf = 0.0f * lw;
+        if (pdf == 0.0f) return false;
+        f = make_f3(0.0f, 0.0f, 0.0f) * wr;
+        return true;
+    }
+    const f3 H = half_vector(b, s, L, V, wt > 0.0f);
+    const f3 Vl = rotate_vector(s.basis, V);
+    const float noh = pt_abs(dot(N, H));
+    pdf = vndf_pdf(Vl, noh, b.Roughness) * lw;
+    if (pdf == 0.0f) return false;
+    const float nov = pt_abs(dot(N, V)), voh = pt_abs(dot(V, H));
+    const float D = distribution_term(b.Roughness, noh);
+    const float G = geometry_term_mod(b.Roughness, nol, nov);
+    const f3 F = fresnel_schlick(b.F0, voh);
+    const float k = nol * D * G;
+    f = (F * k) * wr;
+    return true;
+}
+
 // Camera::GeneratePinholeRay (Camera.hlsli:27-41) with Math::CalculateUV/NDC (Math.hlsli:7-15)
 struct CameraParams {
     f3 Position, Right, Up, Forward;

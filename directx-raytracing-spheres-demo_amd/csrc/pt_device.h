@@ -187,6 +187,10 @@ struct Scratch {
     float4* radiance;     // sum over finished samples (spp > 1)
     uint2* primary_hit;   // cached primary hit for sample regeneration (spp > 1)
     float4* di;           // row N4: direct illumination of the primary surface {rgb, valid} (IsDIEnabled only)
+    // spp > 1, untextured scenes (null otherwise): what the first shading of a pixel's primary surface computes and every later sample
+    // of that pixel would compute again -- {N.xyz, spawn offset} {lobe weights, sphere id} {primary direction, -} per slot.  Written by
+    // the primary pass, read by the looping pass when it regenerates a sample (L2-resident: a lane re-reads its 48 bytes every few steps).
+    float4* primary_cache;
 };
 
 }  // namespace pt

@@ -589,13 +589,19 @@ struct NoTrace {
 // kDI = true (primary passes of the fused schedule): the direct-illumination estimate is made HERE, at the first shading of the
 // primary surface, sharing its material / BSDF evaluation; `trace` casts the shadow ray, `di_rays` counts it.  With kDI = false
 // and fp.di_enabled the estimate is read from scratch.di (written by a kDI pass or, in the split schedule, by di_kernel).
-template <bool kMulti, bool kTex = false, bool kDI = false, typename TraceFn = NoTrace>
+// kCacheMode (kMulti, untextured kernels; Scratch::primary_cache): 1 = the primary pass stores what the first shading of the primary
+// surface computed; 2 = the looping pass restarts a pixel's next sample from that record instead of recomputing the primary ray, the
+// hit frame and the lobe weights (~250 of the ~1100 instructions of a full shading step, once per sample: all samples of a pixel share
+// their primary hit, Raytracing.hlsl:193-198).  The cached values are the ones the full path computes, bit for bit.
+template <bool kMulti, bool kTex = false, bool kDI = false, int kCacheMode = 0, typename TraceFn = NoTrace>
 __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const Scratch& scratch,
                                            float4* __restrict__ out, PathState& ps, float t, uint32_t id, TraceFn&& trace = NoTrace(), uint32_t* di_rays = nullptr)
 {
     const uint32_t slot = ps.slot;
     f3 di_val = make_f3(0.f, 0.f, 0.f);
     bool di_have = false;  // di_val is this pixel's estimate, made in this call
+    bool regen = false;    // kCacheMode 2: this iteration shades a regenerated sample from the pixel's cached record
+    float4 rc0 = make_float4(0.f, 0.f, 0.f, 0.f), rc1 = rc0;
     for (;;) {
         // sampleRadiance so far is (dirty ? scratch : 0); srad_loaded says whether `srad` holds it
         f3 srad = make_f3(0.f, 0.f, 0.f);
@@ -617,7 +623,22 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
             srad = srad + ps.T * env;  // :254
             end_sample = true;
         } else {
-            const HitMaterial hm = hit_material<kTex>(sv, id, ps.o, ps.d, t, ps.bounce == 0);
+            HitMaterial hm;
+            if (kCacheMode == 2 && regen) {
+                // the primary hit of this pixel again: frame and weights from the record (rc0 = {N, offset}, rc1 = {weights, id}), the
+                // material as hit_material forms it (bounce 0: Transmission = Metallic < 1 ? Transmission : 0, Raytracing.hlsl:148)
+                const float4 sp = sv.sph[id];
+                const float4 m0 = sv.mats[id * 4 + 0], m1 = sv.mats[id * 4 + 1], m2 = sv.mats[id * 4 + 2], m3 = sv.mats[id * 4 + 3];
+                hm.hf.N = make_f3(rc0.x, rc0.y, rc0.z);
+                hm.hf.P = mad(sp.w, hm.hf.N, load3(sp));
+                hm.hf.offset = rc0.w;
+                hm.hf.front = dot(hm.hf.N, ps.d) < 0.0f;
+                hm.Ns = hm.hf.front ? hm.hf.N : -hm.hf.N;
+                hm.emission = make_f3(m1.y, m1.z, m1.w) * m1.x;
+                hm.bsdf = bsdf_init_pre(load3(m0), m2.x, m2.y, m2.z, m3.w, m3.z, !(m2.x < 1.0f) ? 0.0f : m2.w, hm.hf.front);
+            } else {
+                hm = hit_material<kTex>(sv, id, ps.o, ps.d, t, ps.bounce == 0);
+            }
             hf = hm.hf;
             f3 emission = hm.emission;
             const f3 Ns = hm.Ns;
@@ -647,18 +668,28 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
                 const Surf surf = surf_init(hf.front, hf.N, Ns);
                 const f3 V = -ps.d;
                 float w[3];
-                lobe_weights(bsdf, surf, V, w);
+                if (kCacheMode == 2 && regen) {
+                    w[0] = rc1.x; w[1] = rc1.y; w[2] = rc1.z;
+                } else {
+                    lobe_weights(bsdf, surf, V, w);
+                    if (kCacheMode == 1 && scratch.primary_cache && ps.bounce == 0 && ps.sample == 0) {
+                        float4* rec = scratch.primary_cache + (size_t)slot * 3u;
+                        rec[0] = make_float4(hf.N.x, hf.N.y, hf.N.z, hf.offset);
+                        rec[1] = make_float4(w[0], w[1], w[2], as_float(id));
+                        rec[2] = make_float4(ps.d.x, ps.d.y, ps.d.z, 0.f);
+                    }
+                }
                 float rnd[4];
                 rnd[0] = rng_float(ps.rng); rnd[1] = rng_float(ps.rng); rnd[2] = rng_float(ps.rng); rnd[3] = rng_float(ps.rng);  // :330
                 int lobe;
                 if (!bsdf_sample(bsdf, surf, V, w, rnd, L, lobe)) {
                     end_sample = true;
                 } else {
-                    const float pdf = bsdf_pdf(bsdf, surf, L, V, w, lobe);
-                    if (pdf == 0.0f) {
+                    float pdf;
+                    f3 f;
+                    if (!bsdf_pdf_eval(bsdf, surf, L, V, w, lobe, pdf, f)) {  // pdf == 0 (:336-339)
                         end_sample = true;
                     } else {
-                        const f3 f = bsdf_eval(bsdf, surf, L, V, w, lobe);
                         if (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) {
                             end_sample = true;
                         } else {
@@ -708,11 +739,21 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
         }
         scratch.radiance[slot] = make_float4(total.x, total.y, total.z, 0.f);
         // ---- regenerate: every sample restarts from the same primary ray / primary hit (:193-198)
-        float tmin, tmax;
-        primary_ray(fp.cam, pr.px, pr.py, ps.o, ps.d, tmin, tmax);
-        const uint2 ph = scratch.primary_hit[slot];
-        t = as_float(ph.x);
-        id = ph.y;
+        if (kCacheMode == 2 && scratch.primary_cache) {
+            const float4* rec = scratch.primary_cache + (size_t)slot * 3u;
+            rc0 = rec[0]; rc1 = rec[1];
+            const float4 rc2 = rec[2];
+            ps.o = fp.cam.Position;
+            ps.d = make_f3(rc2.x, rc2.y, rc2.z);
+            id = as_uint(rc1.w);
+            regen = true;
+        } else {
+            float tmin, tmax;
+            primary_ray(fp.cam, pr.px, pr.py, ps.o, ps.d, tmin, tmax);
+            const uint2 ph = scratch.primary_hit[slot];
+            t = as_float(ph.x);
+            id = ph.y;
+        }
         ps.T = make_f3(1.f, 1.f, 1.f);
         ps.bounce = 0;
         ps.dirty = false;
@@ -912,12 +953,14 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
                         if (kMulti && kPrimary && primary_trace) scratch.primary_hit[i] = make_uint2(as_uint(t), id);
                     }
                     primary_trace = false;
+                    // Scratch::primary_cache: the compacting primary pass of an spp > 1 frame writes the records, the looping pass restarts samples from them
+                    constexpr int kCacheMode = (kMulti && !kTex) ? ((kPrimary && !kLoop) ? 1 : ((kLoop && !kPrimary) ? 2 : 0)) : 0;
                     if (kDI)  // row N4: the first shading of the primary surface also makes its direct-illumination estimate
-                        emit = shade_step<kMulti, kTex, true>(sv, pm, fp, scratch, out, ps, t, id,
+                        emit = shade_step<kMulti, kTex, true, kCacheMode>(sv, pm, fp, scratch, out, ps, t, id,
                                                               [&](f3 so, f3 sd, float& t2, uint32_t& id2) { closest_hit_any<kLds, StackT, kTex>(sv, nodes, sph, ids, so, sd, 0.0f, kInf, stack, blockDim.x, t2, id2); },
                                                               &my_rays);
                     else
-                        emit = shade_step<kMulti, kTex>(sv, pm, fp, scratch, out, ps, t, id);
+                        emit = shade_step<kMulti, kTex, false, kCacheMode>(sv, pm, fp, scratch, out, ps, t, id);
                     if (!emit) break;
                     if (!kLoop && ++iter >= kIters) break;
                     my_rays++;  // a ray spawned and traced inside this kernel (queued rays are counted by counts[])

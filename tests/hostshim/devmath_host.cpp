@@ -133,8 +133,10 @@ void dev_bsdf_step(const PtMaterial* m, int front, const float Ng_[3], const flo
     out->L[0] = L.x; out->L[1] = L.y; out->L[2] = L.z;
     out->pdf = 0.0f; out->f[0] = out->f[1] = out->f[2] = 0.0f;
     if (out->valid) {
-        out->pdf = bsdf_pdf(b, s, L, V, out->weights, out->lobe);
-        f3 f = bsdf_eval(b, s, L, V, out->weights, out->lobe);
+        // what the kernels call: EvaluatePDF + Evaluate in one (shared half vector); f is only formed when pdf != 0 -- the separate
+        // bsdf_eval supplies it otherwise, so that the comparison with the oracle covers both functions
+        f3 f;
+        if (!bsdf_pdf_eval(b, s, L, V, out->weights, out->lobe, out->pdf, f)) f = bsdf_eval(b, s, L, V, out->weights, out->lobe);
         out->f[0] = f.x; out->f[1] = f.y; out->f[2] = f.z;
     }
 }
