@@ -593,130 +593,138 @@ struct NoTrace {
 // surface computed; 2 = the looping pass restarts a pixel's next sample from that record instead of recomputing the primary ray, the
 // hit frame and the lobe weights (~250 of the ~1100 instructions of a full shading step, once per sample: all samples of a pixel share
 // their primary hit, Raytracing.hlsl:193-198).  The cached values are the ones the full path computes, bit for bit.
-template <bool kMulti, bool kTex = false, bool kDI = false, int kCacheMode = 0, typename TraceFn = NoTrace>
-__device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const Scratch& scratch,
-                                           float4* __restrict__ out, PathState& ps, float t, uint32_t id, TraceFn&& trace = NoTrace(), uint32_t* di_rays = nullptr)
+// kMerge (the looping pass at spp > 1): ONE pass through the surface-shading code per call.  The plain form shades the traced hit,
+// and when that ends the sample loops back to shade the regenerated primary hit -- two passes through the most expensive code of the
+// kernel, each for a fraction of the wave's lanes (92 % of C3's bounce rays miss: the first pass runs for the few lanes that hit).
+// Merged, a lane whose ray missed finishes its sample first and then shades its regenerated primary hit TOGETHER with the lanes that
+// hit; a lane whose sample ends in the surface code returns kShadePending and starts its next call there (no ray to trace in between).
+// Per-lane order of operations, RNG draws and arithmetic are unchanged.  `pending` in: the previous call returned kShadePending.
+enum : int { kShadeDone = 0, kShadeRay = 1, kShadePending = 2 };
+
+template <bool kMulti, bool kTex = false, bool kDI = false, int kCacheMode = 0, bool kMerge = false, typename TraceFn = NoTrace>
+__device__ __forceinline__ int shade_step_ex(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const Scratch& scratch,
+                                             float4* __restrict__ out, PathState& ps, float t, uint32_t id, bool pending, TraceFn&& trace = NoTrace(), uint32_t* di_rays = nullptr)
 {
+    static_assert(!kMerge || (kMulti && !kDI), "the merged form is the looping pass of spp > 1 frames");
     const uint32_t slot = ps.slot;
     f3 di_val = make_f3(0.f, 0.f, 0.f);
     bool di_have = false;  // di_val is this pixel's estimate, made in this call
-    bool regen = false;    // kCacheMode 2: this iteration shades a regenerated sample from the pixel's cached record
+    bool regen = false;    // kCacheMode 2: the surface being shaded is a regenerated primary hit described by the pixel's cached record
     float4 rc0 = make_float4(0.f, 0.f, 0.f, 0.f), rc1 = rc0;
-    for (;;) {
-        // sampleRadiance so far is (dirty ? scratch : 0); srad_loaded says whether `srad` holds it
-        f3 srad = make_f3(0.f, 0.f, 0.f);
-        bool srad_loaded = false, srad_changed = false;
-        bool end_sample = false;
-        f3 L = make_f3(0.f, 0.f, 0.f);
-        HitFrame hf;
-        if (id == kMissId) {
-            f3 env;
-            if (kTex && sv.env_tex != kNoTexture)
-                env = sv.env_cube ? environment_cube(sv.tex + sv.env_tex, sv.env_xf, ps.d) : environment_texture(sv.tex[sv.env_tex], sv.env_xf, ps.d);
-            else env = environment_color(sv.env[0], sv.env[1], sv.env[2], sv.env[3], ps.d);
-            if (ps.bounce == 0) {  // primary miss: pixel = environment (GBufferGeneration.hlsl:223-227; Raytracing.hlsl:249-252)
-                out[slot_to_pixel(pm, slot).out_index] = make_float4(env.x, env.y, env.z, 1.0f);
-                return false;
-            }
-            if (ps.dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
-            srad_loaded = true;
-            srad = srad + ps.T * env;  // :254
-            end_sample = true;
-        } else {
-            HitMaterial hm;
-            if (kCacheMode == 2 && regen) {
-                // the primary hit of this pixel again: frame and weights from the record (rc0 = {N, offset}, rc1 = {weights, id}), the
-                // material as hit_material forms it (bounce 0: Transmission = Metallic < 1 ? Transmission : 0, Raytracing.hlsl:148)
-                const float4 sp = sv.sph[id];
-                const float4 m0 = sv.mats[id * 4 + 0], m1 = sv.mats[id * 4 + 1], m2 = sv.mats[id * 4 + 2], m3 = sv.mats[id * 4 + 3];
-                hm.hf.N = make_f3(rc0.x, rc0.y, rc0.z);
-                hm.hf.P = mad(sp.w, hm.hf.N, load3(sp));
-                hm.hf.offset = rc0.w;
-                hm.hf.front = dot(hm.hf.N, ps.d) < 0.0f;
-                hm.Ns = hm.hf.front ? hm.hf.N : -hm.hf.N;
-                hm.emission = make_f3(m1.y, m1.z, m1.w) * m1.x;
-                hm.bsdf = bsdf_init_pre(load3(m0), m2.x, m2.y, m2.z, m3.w, m3.z, !(m2.x < 1.0f) ? 0.0f : m2.w, hm.hf.front);
-            } else {
-                hm = hit_material<kTex>(sv, id, ps.o, ps.d, t, ps.bounce == 0);
-            }
-            hf = hm.hf;
-            f3 emission = hm.emission;
-            const f3 Ns = hm.Ns;
-            const Bsdf& bsdf = hm.bsdf;
-            // Sphere-light direct illumination (row N4) covers what the reflective lobes of the primary surface receive from the
-            // emitters, so the emission of a first-bounce hit reached through them is dropped (Raytracing.hlsl:302).  The flag
-            // is "the pixel has a primary surface", not the reference's any(DI > 0): with a one-sample estimator DI = 0 is an
-            // ordinary sample value and conditioning on it would bias the frame upward; and a sample that left through the
-            // transmission lobe keeps its emission, because DI evaluates the reflective lobes only.
-            if (fp.di_enabled && ps.bounce == 1 && !ps.via_t) emission = make_f3(0.f, 0.f, 0.f);
-            if (kDI && fp.di_enabled && ps.bounce == 0 && (!kMulti || ps.sample == 0) && !di_have) {
-                const PixelRef dpr = slot_to_pixel(pm, slot);
-                di_val = di_estimate<kTex>(sv, fp, dpr.px, dpr.py, id, ps.d, hm, trace, *di_rays);
-                di_have = true;
-            }
-            const bool t_finite = is_finite(ps.T.x) && is_finite(ps.T.y) && is_finite(ps.T.z);
-            if (emission.x != 0.0f || emission.y != 0.0f || emission.z != 0.0f || !t_finite) {
-                if (ps.dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
-                srad_loaded = true;
-                srad = srad + ps.T * emission;  // :320
-                srad_changed = true;
-            }
-            const bool last = ps.bounce == fp.bounces;
-            if (last && (!kMulti || ps.sample + 1 == fp.spp)) {
-                end_sample = true;  // the sample drawn on the final iteration is never used and no later sample reads the RNG
-            } else {
-                const Surf surf = surf_init(hf.front, hf.N, Ns);
-                const f3 V = -ps.d;
-                float w[3];
-                if (kCacheMode == 2 && regen) {
-                    w[0] = rc1.x; w[1] = rc1.y; w[2] = rc1.z;
-                } else {
-                    lobe_weights(bsdf, surf, V, w);
-                    if (kCacheMode == 1 && scratch.primary_cache && ps.bounce == 0 && ps.sample == 0) {
-                        float4* rec = scratch.primary_cache + (size_t)slot * 3u;
-                        rec[0] = make_float4(hf.N.x, hf.N.y, hf.N.z, hf.offset);
-                        rec[1] = make_float4(w[0], w[1], w[2], as_float(id));
-                        rec[2] = make_float4(ps.d.x, ps.d.y, ps.d.z, 0.f);
-                    }
-                }
-                float rnd[4];
-                rnd[0] = rng_float(ps.rng); rnd[1] = rng_float(ps.rng); rnd[2] = rng_float(ps.rng); rnd[3] = rng_float(ps.rng);  // :330
-                int lobe;
-                if (!bsdf_sample(bsdf, surf, V, w, rnd, L, lobe)) {
-                    end_sample = true;
-                } else {
-                    float pdf;
-                    f3 f;
-                    if (!bsdf_pdf_eval(bsdf, surf, L, V, w, lobe, pdf, f)) {  // pdf == 0 (:336-339)
-                        end_sample = true;
-                    } else {
-                        if (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) {
-                            end_sample = true;
-                        } else {
-                            { const float inv_pdf = 1.0f / pdf; ps.T = ps.T * (f * inv_pdf); }  // :346
-                            if (ps.bounce == 0) ps.via_t = lobe == kLobeTransmission;
-                            if (fp.rr_enabled && ps.bounce > 3) {                     // :348-356
-                                const float p = pt_max(ps.T.x, pt_max(ps.T.y, ps.T.z));
-                                if (rng_float(ps.rng) >= p) end_sample = true;
-                                else ps.T = ps.T * (1.0f / p);
-                            }
-                            if (!end_sample && luminance(ps.T) <= fp.throughput_threshold) end_sample = true;  // :361
-                            if (last) end_sample = true;
-                        }
-                    }
-                }
-            }
-        }
-        if (!end_sample) {
-            // spawn the next ray (Raytracing.hlsl:219-224)
-            ps.o = spawn_origin(hf.P, hf.N, hf.offset, L);
-            ps.d = L;
-            ps.bounce++;
-            if (srad_changed) { scratch.sample_rad[slot] = make_float4(srad.x, srad.y, srad.z, 0.f); ps.dirty = true; }
-            if (kDI && di_have) scratch.di[slot] = make_float4(di_val.x, di_val.y, di_val.z, 0.f);  // the pass that finishes the pixel adds it
+    // sampleRadiance so far is (dirty ? scratch : 0); srad_loaded says whether `srad` holds it
+    f3 srad = make_f3(0.f, 0.f, 0.f);
+    bool srad_loaded = false, srad_changed = false;
+    bool end_sample = false;
+    f3 L = make_f3(0.f, 0.f, 0.f);
+    HitFrame hf;
+
+    // the ray missed: sampleRadiance += T * environment (:242-259); a primary miss writes the pixel and returns true
+    auto shade_miss = [&]() -> bool {
+        f3 env;
+        if (kTex && sv.env_tex != kNoTexture)
+            env = sv.env_cube ? environment_cube(sv.tex + sv.env_tex, sv.env_xf, ps.d) : environment_texture(sv.tex[sv.env_tex], sv.env_xf, ps.d);
+        else env = environment_color(sv.env[0], sv.env[1], sv.env[2], sv.env[3], ps.d);
+        if (ps.bounce == 0) {  // primary miss: pixel = environment (GBufferGeneration.hlsl:223-227; Raytracing.hlsl:249-252)
+            out[slot_to_pixel(pm, slot).out_index] = make_float4(env.x, env.y, env.z, 1.0f);
             return true;
         }
-        // ---- end of sample: radiance += sampleRadiance (:373)
+        if (ps.dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
+        srad_loaded = true;
+        srad = srad + ps.T * env;  // :254
+        end_sample = true;
+        return false;
+    };
+
+    // the ray hit sphere `id` at t (or: the regenerated primary hit): material, emission, lobe choice, sample, pdf, f, throughput,
+    // Russian roulette, cut-off (:293-364).  Sets end_sample, or leaves L / hf for the spawn.
+    auto shade_surface = [&]() {
+        HitMaterial hm;
+        if (kCacheMode == 2 && regen) {
+            // the primary hit of this pixel again: frame and weights from the record (rc0 = {N, offset}, rc1 = {weights, id}), the
+            // material as hit_material forms it (bounce 0: Transmission = Metallic < 1 ? Transmission : 0, Raytracing.hlsl:148)
+            const float4 sp = sv.sph[id];
+            const float4 m0 = sv.mats[id * 4 + 0], m1 = sv.mats[id * 4 + 1], m2 = sv.mats[id * 4 + 2], m3 = sv.mats[id * 4 + 3];
+            hm.hf.N = make_f3(rc0.x, rc0.y, rc0.z);
+            hm.hf.P = mad(sp.w, hm.hf.N, load3(sp));
+            hm.hf.offset = rc0.w;
+            hm.hf.front = dot(hm.hf.N, ps.d) < 0.0f;
+            hm.Ns = hm.hf.front ? hm.hf.N : -hm.hf.N;
+            hm.emission = make_f3(m1.y, m1.z, m1.w) * m1.x;
+            hm.bsdf = bsdf_init_pre(load3(m0), m2.x, m2.y, m2.z, m3.w, m3.z, !(m2.x < 1.0f) ? 0.0f : m2.w, hm.hf.front);
+        } else {
+            hm = hit_material<kTex>(sv, id, ps.o, ps.d, t, ps.bounce == 0);
+        }
+        hf = hm.hf;
+        f3 emission = hm.emission;
+        const f3 Ns = hm.Ns;
+        const Bsdf& bsdf = hm.bsdf;
+        // Sphere-light direct illumination (row N4) covers what the reflective lobes of the primary surface receive from the
+        // emitters, so the emission of a first-bounce hit reached through them is dropped (Raytracing.hlsl:302).  The flag
+        // is "the pixel has a primary surface", not the reference's any(DI > 0): with a one-sample estimator DI = 0 is an
+        // ordinary sample value and conditioning on it would bias the frame upward; and a sample that left through the
+        // transmission lobe keeps its emission, because DI evaluates the reflective lobes only.
+        if (fp.di_enabled && ps.bounce == 1 && !ps.via_t) emission = make_f3(0.f, 0.f, 0.f);
+        if (kDI && fp.di_enabled && ps.bounce == 0 && (!kMulti || ps.sample == 0) && !di_have) {
+            const PixelRef dpr = slot_to_pixel(pm, slot);
+            di_val = di_estimate<kTex>(sv, fp, dpr.px, dpr.py, id, ps.d, hm, trace, *di_rays);
+            di_have = true;
+        }
+        const bool t_finite = is_finite(ps.T.x) && is_finite(ps.T.y) && is_finite(ps.T.z);
+        if (emission.x != 0.0f || emission.y != 0.0f || emission.z != 0.0f || !t_finite) {
+            if (ps.dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
+            srad_loaded = true;
+            srad = srad + ps.T * emission;  // :320
+            srad_changed = true;
+        }
+        const bool last = ps.bounce == fp.bounces;
+        if (last && (!kMulti || ps.sample + 1 == fp.spp)) {
+            end_sample = true;  // the sample drawn on the final iteration is never used and no later sample reads the RNG
+            return;
+        }
+        const Surf surf = surf_init(hf.front, hf.N, Ns);
+        const f3 V = -ps.d;
+        float w[3];
+        if (kCacheMode == 2 && regen) {
+            w[0] = rc1.x; w[1] = rc1.y; w[2] = rc1.z;
+        } else {
+            lobe_weights(bsdf, surf, V, w);
+            if (kCacheMode == 1 && scratch.primary_cache && ps.bounce == 0 && ps.sample == 0) {
+                float4* rec = scratch.primary_cache + (size_t)slot * 3u;
+                rec[0] = make_float4(hf.N.x, hf.N.y, hf.N.z, hf.offset);
+                rec[1] = make_float4(w[0], w[1], w[2], as_float(id));
+                rec[2] = make_float4(ps.d.x, ps.d.y, ps.d.z, 0.f);
+            }
+        }
+        float rnd[4];
+        rnd[0] = rng_float(ps.rng); rnd[1] = rng_float(ps.rng); rnd[2] = rng_float(ps.rng); rnd[3] = rng_float(ps.rng);  // :330
+        int lobe;
+        if (!bsdf_sample(bsdf, surf, V, w, rnd, L, lobe)) { end_sample = true; return; }
+        float pdf;
+        f3 f;
+        if (!bsdf_pdf_eval(bsdf, surf, L, V, w, lobe, pdf, f)) { end_sample = true; return; }  // pdf == 0 (:336-339)
+        if (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) { end_sample = true; return; }
+        { const float inv_pdf = 1.0f / pdf; ps.T = ps.T * (f * inv_pdf); }  // :346
+        if (ps.bounce == 0) ps.via_t = lobe == kLobeTransmission;
+        if (fp.rr_enabled && ps.bounce > 3) {                     // :348-356
+            const float p = pt_max(ps.T.x, pt_max(ps.T.y, ps.T.z));
+            if (rng_float(ps.rng) >= p) end_sample = true;
+            else ps.T = ps.T * (1.0f / p);
+        }
+        if (!end_sample && luminance(ps.T) <= fp.throughput_threshold) end_sample = true;  // :361
+        if (last) end_sample = true;
+    };
+
+    // spawn the next ray (Raytracing.hlsl:219-224)
+    auto spawn = [&]() {
+        ps.o = spawn_origin(hf.P, hf.N, hf.offset, L);
+        ps.d = L;
+        ps.bounce++;
+        if (srad_changed) { scratch.sample_rad[slot] = make_float4(srad.x, srad.y, srad.z, 0.f); ps.dirty = true; }
+        if (kDI && di_have) scratch.di[slot] = make_float4(di_val.x, di_val.y, di_val.z, 0.f);  // the pass that finishes the pixel adds it
+    };
+
+    // end of sample: radiance += sampleRadiance (:373); true = that was the pixel's last sample, the pixel has been written (:378-385)
+    auto finish_sample = [&]() -> bool {
         if (!srad_loaded) {
             if (ps.dirty) { const float4 s = scratch.sample_rad[slot]; srad = load3(s); }
         }
@@ -724,8 +732,7 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
         if (kMulti && ps.sample > 0) { const float4 r = scratch.radiance[slot]; acc = load3(r); }
         const f3 total = acc + srad;
         ps.sample++;
-        const PixelRef pr = slot_to_pixel(pm, slot);
-        if (!kMulti || ps.sample == fp.spp) {  // :378-385
+        if (!kMulti || ps.sample == fp.spp) {
             f3 res = make_f3(0.f, 0.f, 0.f);
             if (is_finite(total.x) && is_finite(total.y) && is_finite(total.z)) {
                 res = total * fp.inv_spp;
@@ -734,11 +741,15 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
                 if (kDI && di_have) res = res + di_val;
                 else { const float4 di = scratch.di[slot]; res = res + load3(di); }
             }
-            out[pr.out_index] = make_float4(res.x, res.y, res.z, 1.0f);
-            return false;
+            out[slot_to_pixel(pm, slot).out_index] = make_float4(res.x, res.y, res.z, 1.0f);
+            return true;
         }
         scratch.radiance[slot] = make_float4(total.x, total.y, total.z, 0.f);
-        // ---- regenerate: every sample restarts from the same primary ray / primary hit (:193-198)
+        return false;
+    };
+
+    // regenerate: every sample restarts from the same primary ray / primary hit (:193-198)
+    auto regenerate = [&]() {
         if (kCacheMode == 2 && scratch.primary_cache) {
             const float4* rec = scratch.primary_cache + (size_t)slot * 3u;
             rc0 = rec[0]; rc1 = rec[1];
@@ -748,6 +759,7 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
             id = as_uint(rc1.w);
             regen = true;
         } else {
+            const PixelRef pr = slot_to_pixel(pm, slot);
             float tmin, tmax;
             primary_ray(fp.cam, pr.px, pr.py, ps.o, ps.d, tmin, tmax);
             const uint2 ph = scratch.primary_hit[slot];
@@ -758,7 +770,39 @@ __device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& 
         ps.bounce = 0;
         ps.dirty = false;
         ps.via_t = false;
+        srad = make_f3(0.f, 0.f, 0.f);
+        srad_loaded = false; srad_changed = false;
+        end_sample = false;
+    };
+
+    if (kMerge) {
+        if (pending) {
+            regenerate();
+        } else if (id == kMissId) {
+            if (shade_miss()) return kShadeDone;
+            if (finish_sample()) return kShadeDone;
+            regenerate();
+        }
+        shade_surface();  // the traced hit, or the regenerated primary hit of a lane whose ray missed / whose last call ended its sample
+        if (!end_sample) { spawn(); return kShadeRay; }
+        return finish_sample() ? kShadeDone : kShadePending;
     }
+    for (;;) {
+        if (id == kMissId) { if (shade_miss()) return kShadeDone; }
+        else shade_surface();
+        if (!end_sample) { spawn(); return kShadeRay; }
+        if (finish_sample()) return kShadeDone;
+        regenerate();
+    }
+}
+
+// One iteration of the bounce-loop body for a path whose ray (ps.o, ps.d) has been traced to (t, id), as the kernels outside the merged
+// looping pass use it: true = ps holds a new ray that must be traced, false = the pixel is finished.
+template <bool kMulti, bool kTex = false, bool kDI = false, int kCacheMode = 0, typename TraceFn = NoTrace>
+__device__ __forceinline__ bool shade_step(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const Scratch& scratch,
+                                           float4* __restrict__ out, PathState& ps, float t, uint32_t id, TraceFn&& trace = NoTrace(), uint32_t* di_rays = nullptr)
+{
+    return shade_step_ex<kMulti, kTex, kDI, kCacheMode, false>(sv, pm, fp, scratch, out, ps, t, id, false, trace, di_rays) == kShadeRay;
 }
 
 __device__ __forceinline__ PathState load_path(const RayQueue& q, uint32_t i)
@@ -939,7 +983,20 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
             } else {
                 ps = load_path(qin, i);
             }
-            if (live) {
+            constexpr bool kMerged = kLoop && kMulti && !kPrimary;  // (shade_step_ex: one pass through the surface code per iteration)
+            if (kMerged) {
+                constexpr int kCacheMode = kTex ? 0 : 2;
+                bool pending = false;
+                for (;;) {
+                    float t = 0.0f;
+                    uint32_t id = kMissId;
+                    if (!pending) closest_hit_any<kLds, StackT, kTex>(sv, nodes, sph, ids, ps.o, ps.d, 0.0f, kInf, stack, blockDim.x, t, id);
+                    const int r = shade_step_ex<true, kTex, false, kCacheMode, true>(sv, pm, fp, scratch, out, ps, t, id, pending);
+                    if (r == kShadeDone) break;
+                    pending = r == kShadePending;
+                    if (!pending) my_rays++;  // a ray spawned and traced inside this kernel
+                }
+            } else if (live) {
                 bool primary_trace = kPrimary;
                 uint32_t iter = 0;
                 for (;;) {
