@@ -262,7 +262,7 @@ PT_HD void primary_ray(const CameraParams& cam, uint32_t px, uint32_t py, f3& o,
     float ny = pt_fma(v, -2.0f, 1.0f);
     f3 dir = mad(ny, cam.Up, cam.Right * nx) + cam.Forward;
     dir = normalize(dir);
-    float inv_cos = 1.0f / dot(cam.ForwardN, dir);
+    float inv_cos = pt_rcp(dot(cam.ForwardN, dir));
     o = cam.Position;
     d = dir;
     tmin = cam.Near * inv_cos;

@@ -24,7 +24,7 @@ PT_HD LightSample sample_sphere_cone(f3 P, f3 C, float r, float u1, float u2)
     const f3 w = C - P;
     const float d2 = dot(w, w), r2 = r * r;
     if (!(d2 > r2)) return s;
-    const f3 wn = w * (1.0f / pt_sqrt(d2));
+    const f3 wn = w * pt_rcp(pt_sqrt(d2));
     const float sin2 = r2 / d2;
     const float cos_max = sqrt01(1.0f - sin2);
     const float omc = sin2 / (1.0f + cos_max);       // 1 - cos(theta_max)

@@ -34,16 +34,23 @@ PT_HD f3 operator-(f3 a) { return make_f3(-a.x, -a.y, -a.z); }
 // s*a + b, one fma per component
 PT_HD f3 mad(float s, f3 a, f3 b) { return make_f3(pt_fma(s, a.x, b.x), pt_fma(s, a.y, b.y), pt_fma(s, a.z, b.z)); }
 PT_HD float dot(f3 a, f3 b) { return pt_fma(a.z, b.z, pt_fma(a.y, b.y, a.x * b.x)); }
-PT_HD float pt_sqrt(float x) { return __builtin_sqrtf(x); }  // IEEE correctly rounded (hipcc default)
-PT_HD f3 normalize(f3 a) { float inv = 1.0f / pt_sqrt(dot(a, a)); return a * inv; }
+PT_HD uint32_t as_uint(float f) { return __builtin_bit_cast(uint32_t, f); }
+PT_HD float as_float(uint32_t u) { return __builtin_bit_cast(float, u); }
+// Square root, reciprocal and 0.5 / x, IEEE correctly rounded (hipcc's default expansions: 16, 11 and 11 instructions, branch-free).
+// Shorter forms exist -- v_rcp_f32 + ONE Newton step is the correctly rounded reciprocal of every normal operand whose reciprocal is
+// normal, v_sqrt_f32 + the neighbour fix-up without the rescaling is exact from 2^-96 up (all 2^32 operands checked on the GPU,
+// tools/experiments/exact_math.hip) -- but the branch to the full expansion that the remaining operands need costs more scalar
+// instructions and scheduling freedom than the vector instructions it saves: C2 0.081 -> 0.083 ms, C3 3.12 -> 3.17 (tools/experiments/README.md).
+PT_HD float pt_sqrt(float x) { return __builtin_sqrtf(x); }
+PT_HD float pt_rcp(float x) { return 1.0f / x; }
+PT_HD float pt_half_rcp(float x) { return 0.5f / x; }
+PT_HD f3 normalize(f3 a) { float inv = pt_rcp(pt_sqrt(dot(a, a))); return a * inv; }
 PT_HD float pt_abs(float x) { return __builtin_fabsf(x); }
 PT_HD float pt_max(float a, float b) { return a > b ? a : b; }
 PT_HD float pt_min(float a, float b) { return a < b ? a : b; }
 PT_HD float saturate(float x) { return !(x > 0.0f) ? 0.0f : (x > 1.0f ? 1.0f : x); }  // NaN -> 0 as HLSL
 PT_HD float sqrt01(float x) { return pt_sqrt(saturate(x)); }
 PT_HD float sign(float x) { return x >= 0.0f ? 1.0f : -1.0f; }  // Math::Sign, Sign(0) = +1
-PT_HD uint32_t as_uint(float f) { return __builtin_bit_cast(uint32_t, f); }
-PT_HD float as_float(uint32_t u) { return __builtin_bit_cast(float, u); }
 PT_HD bool is_finite(float x) { return (as_uint(x) & 0x7F800000u) != 0x7F800000u; }
 PT_HD float pt_floor(float x) { return __builtin_floorf(x); }
 
@@ -140,7 +147,7 @@ struct Basis {
 PT_HD Basis get_basis(f3 N)
 {
     float sz = sign(N.z);
-    float a = 1.0f / (sz + N.z);
+    float a = pt_rcp(sz + N.z);
     float ya = N.y * a;
     float b = N.x * ya;
     float c = N.x * sz;
@@ -205,7 +212,7 @@ PT_HD float vndf_pdf(f3 Vl, float noh, float roughness)
     float m2 = m * m;
     float nov = pt_abs(Vl.z);
     float d = distribution_term(roughness, noh);
-    return d * (0.5f / (nov + pt_sqrt(pt_fma(1.0f - m2, nov * nov, m2))));  // D G1 / (4 NoV), one division
+    return d * pt_half_rcp(nov + pt_sqrt(pt_fma(1.0f - m2, nov * nov, m2)));  // D G1 / (4 NoV), one division (0.5 / x)
 }
 
 PT_HD float geometry_term_mod(float roughness, float nol, float nov)
@@ -214,7 +221,7 @@ PT_HD float geometry_term_mod(float roughness, float nol, float nov)
     float m2 = m * m;
     float a = nov * sqrt01(pt_fma(pt_fma(-m2, nol, nol), nol, m2));
     float b = nol * sqrt01(pt_fma(pt_fma(-m2, nov, nov), nov, m2));
-    return 0.5f / (a + b);
+    return pt_half_rcp(a + b);  // 0.5 / (a + b)
 }
 
 PT_HD float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }

@@ -60,7 +60,7 @@ PT_HD f3 sphere_tangent(f3 n)
 {
     const float l2 = pt_fma(n.z, n.z, n.x * n.x);
     if (!(l2 > 0.0f)) return make_f3(0.0f, 0.0f, 0.0f);
-    const float inv = 1.0f / pt_sqrt(l2);
+    const float inv = pt_rcp(pt_sqrt(l2));
     return make_f3(n.z * inv, 0.0f, -n.x * inv);
 }
 

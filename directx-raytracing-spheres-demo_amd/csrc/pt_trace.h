@@ -703,12 +703,12 @@ __device__ __forceinline__ int shade_step_ex(const SceneView& sv, const PixelMap
         f3 f;
         if (!bsdf_pdf_eval(bsdf, surf, L, V, w, lobe, pdf, f)) { end_sample = true; return; }  // pdf == 0 (:336-339)
         if (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) { end_sample = true; return; }
-        { const float inv_pdf = 1.0f / pdf; ps.T = ps.T * (f * inv_pdf); }  // :346
+        { const float inv_pdf = pt_rcp(pdf); ps.T = ps.T * (f * inv_pdf); }  // :346
         if (ps.bounce == 0) ps.via_t = lobe == kLobeTransmission;
         if (fp.rr_enabled && ps.bounce > 3) {                     // :348-356
             const float p = pt_max(ps.T.x, pt_max(ps.T.y, ps.T.z));
             if (rng_float(ps.rng) >= p) end_sample = true;
-            else ps.T = ps.T * (1.0f / p);
+            else ps.T = ps.T * pt_rcp(p);
         }
         if (!end_sample && luminance(ps.T) <= fp.throughput_threshold) end_sample = true;  // :361
         if (last) end_sample = true;
