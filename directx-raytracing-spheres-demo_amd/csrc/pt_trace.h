@@ -853,6 +853,10 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
     // than that.  Measured on C2: 1 bounce 0.1165, 2 bounces 0.107, 3 bounces 0.116, 4 bounces 0.123 ms per frame (kInline2 is
     // the host's switch; it is on for every 1-spp frame of the fused schedule).
     constexpr uint32_t kIters = (kPrimary && !kLoop && !kMulti && kInline2) ? 2u : 1u;
+    // The looping pass of a 1-spp frame is a chain of dependent bounces on a few thousand nearly empty waves that share their SIMDs with the
+    // primary passes of the frames behind it.  VALU issue is arbitrated by priority, then age (MI355X_MICROARCH.md), and those primary waves are
+    // usually the older ones: raised priority lets the chain run as if alone, for a handful of issue slots taken from the throughput-bound waves.
+    if (kLoop && !kMulti && !kPrimary) __builtin_amdgcn_s_setprio(3);
     extern __shared__ float4 smem[];
     __shared__ uint32_t s_wave_count[kFusedThreads / 64];
     __shared__ uint32_t s_block_base;
