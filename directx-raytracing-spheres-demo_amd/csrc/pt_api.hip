@@ -1186,6 +1186,7 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
         const float f0d = pt::dielectric_f0(m.IOR), inv_ior = 1.0f / m.IOR;
         std::memcpy(&m._pad[0], &f0d, 4);
         std::memcpy(&m._pad[1], &inv_ior, 4);
+        m.AlphaMode &= ~kMaterialHasMaps;  // (bit 31 of the device copy is pt_set_textures' "has texture maps" flag; the alpha class comes from the host)
     }
     PT_HIP(c, hipMemcpyAsync(c->d_mats, mats.data(), (size_t)n * sizeof(PtMaterial), hipMemcpyHostToDevice, c->stream));
     if (c->n_lights) PT_HIP(c, hipMemcpyAsync(c->d_lights, lights.data(), lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -1519,6 +1520,8 @@ PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_tex
         PT_HIP(c, sync_all(c));
         free_textures(c);
         for (auto& am : c->alpha_mats) am.base_map = ~0u;
+        PT_HIP(c, launch_material_map_flags(c->d_mats, nullptr, c->n, c->stream));
+        PT_HIP(c, hipStreamSynchronize(c->stream));
         return update_alpha_classes(c);
     }
     if (!textures) return fail(c, PT_ERR_INVALID_ARG, "pt_set_textures: null pointer");
@@ -1580,6 +1583,8 @@ PtStatus pt_set_textures(PtContext* c, const PtTexture* textures, uint32_t n_tex
     PT_HIP(c, hipMemcpy(c->d_rot, c->h_rot.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice));  // (everything was synchronised above)
     c->rot_master_gen = ++c->rot_gen;  // the master copy is current; lanes take private copies from the next pt_update_rotations on
     c->has_textures = true;
+    PT_HIP(c, launch_material_map_flags(c->d_mats, c->d_tex_maps, n, c->stream));  // kMaterialHasMaps in the device materials
+    PT_HIP(c, hipStreamSynchronize(c->stream));
     for (auto& am : c->alpha_mats) am.base_map = maps[(size_t)am.id * 8u + kMapBaseColor];
     return update_alpha_classes(c);  // a base-colour map turns a non-opaque sphere's alpha test into a per-crossing one
 }

@@ -29,6 +29,7 @@ constexpr uint32_t kFlagSampleMask = 0xFFFFu;
 constexpr uint32_t kFlagDirty = 1u << 24;
 constexpr uint32_t kFlagViaTransmission = 1u << 25;  // row N4: this sample left the primary surface through the transmission lobe
 constexpr uint32_t kMissId = 0xFFFFFFFFu;
+constexpr uint32_t kMaterialHasMaps = 0x80000000u;  // device copy of PtMaterial::AlphaMode, bit 31: the sphere has texture maps (pt_set_textures)
 
 // Alpha-tested hits (DESIGN.md spec S10; Scene.ixx:242-243, RaytracingHelpers.hlsli:19-43, ShadingHelpers.hlsli:105-115).  A sphere whose
 // AlphaMode is not Opaque is classified on the host when materials or texture maps change:

@@ -38,6 +38,8 @@ hipError_t launch_bounce(const SceneView& sv, const PixelMap& pm, const FramePar
 hipError_t launch_unpack_tiles(const float4* packed, float4* frame, uint32_t w, uint32_t h, uint32_t ts, uint32_t tiles_x, uint32_t first0,
                                uint32_t run, uint32_t stride, uint32_t n_parts, uint64_t part_stride, bool rgb, hipStream_t stream);
 hipError_t launch_pack_rgb(const float4* src, float* dst, uint64_t n, hipStream_t stream);
+// bit 31 of the AlphaMode word of every device material := the sphere has texture maps (tex_maps null: none has)
+hipError_t launch_material_map_flags(float4* mats, const uint32_t* tex_maps, uint32_t n, hipStream_t stream);
 // alpha-tested hits: out[k] = sorted_id[k] | alpha_class[sorted_id[k]] << 30 (the leaf ids of SceneView::sorted_id)
 hipError_t launch_leaf_ids(const uint32_t* sorted_id, const uint32_t* alpha_class, uint32_t n, uint32_t* out, hipStream_t stream);
 

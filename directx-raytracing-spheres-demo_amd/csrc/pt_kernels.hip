@@ -466,6 +466,16 @@ __global__ void flush_counters_kernel(uint32_t* counts, uint32_t n_counts, unsig
     if (blockIdx.x == 0) fold_counters(counts, n_counts, tail, totals, host_counts);
 }
 
+// bit 31 of every material's AlphaMode word (device copy) := the sphere has texture maps (tex_maps[i * 8 + 7]; null = no sphere has)
+__global__ void material_map_flag_kernel(uint32_t* __restrict__ mats_words, const uint32_t* __restrict__ tex_maps, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t w = mats_words[(size_t)i * 16u + 12u] & ~kMaterialHasMaps;
+        if (tex_maps && tex_maps[(size_t)i * 8u + 7u]) w |= kMaterialHasMaps;
+        mats_words[(size_t)i * 16u + 12u] = w;
+    }
+}
+
 // leaf ids the traversal reads: Morton order -> original id | alpha class << 30 (pt_device.h)
 __global__ void leaf_ids_kernel(const uint32_t* __restrict__ sorted_id, const uint32_t* __restrict__ alpha_class, uint32_t n, uint32_t* __restrict__ out)
 {
@@ -651,6 +661,13 @@ hipError_t launch_di(const SceneView& sv, const PixelMap& pm, const FrameParams&
     else { if (small) PT_DI(false, uint16_t); else PT_DI(false, uint32_t); }
 #undef PT_DI
 #undef PT_DI2
+    return hipGetLastError();
+}
+
+hipError_t launch_material_map_flags(float4* mats, const uint32_t* tex_maps, uint32_t n, hipStream_t stream)
+{
+    const uint32_t grid = (n + 255u) / 256u < 4096u ? (n + 255u) / 256u : 4096u;
+    hipLaunchKernelGGL(material_map_flag_kernel, dim3(grid ? grid : 1u), dim3(256), 0, stream, reinterpret_cast<uint32_t*>(mats), tex_maps, n);
     return hipGetLastError();
 }
 

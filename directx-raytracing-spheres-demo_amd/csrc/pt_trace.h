@@ -156,30 +156,37 @@ __device__ __forceinline__ void wide_visit(const float4* __restrict__ wide, int&
 // ------------------------------------------------------------------------------------------------ alpha-tested hits (spec S10)
 // texture coordinates of the point of sphere `id` whose outward world-space normal is N (spec S6): q = the object's rotation,
 // n_mesh = the mesh-space normal the coordinates (and the tangent) derive from
-__device__ __forceinline__ f2 hit_uv(const SceneView& sv, uint32_t id, f3 N, float4& q, f3& n_mesh)
+__device__ __forceinline__ f2 hit_uv_rot(const float4* __restrict__ rot, uint32_t id, f3 N, float4& q, f3& n_mesh)
 {
-    q = sv.rot[id];
+    q = rot[id];
     const f3 n_obj = quat_rotate(-q.x, -q.y, -q.z, q.w, N);  // world -> object: the conjugate rotation
     // ObjectToWorld = diag(1, 1, -1) * pose (Scene.ixx:197-199): the mesh-space normal is the z mirror of the object-space
     // one (settled against the reference's screenshot with its own Earth map: without it the continents are mirrored)
     n_mesh = make_f3(n_obj.x, n_obj.y, -n_obj.z);
     return sphere_uv(n_mesh);
 }
+__device__ __forceinline__ f2 hit_uv(const SceneView& sv, uint32_t id, f3 N, float4& q, f3& n_mesh) { return hit_uv_rot(sv.rot, id, N, q, n_mesh); }
 
 // IsOpaque (ShadingHelpers.hlsli:105-115) for the crossing at parameter t of a kAlphaTested sphere: alpha = BaseColor.a * the
 // base-colour map's alpha at the crossing's texture coordinates (the class says EvaluateBaseColor samples, :61-72); accepted iff
-// alpha >= AlphaCutoff.
-__device__ __forceinline__ bool crossing_is_opaque(const SceneView& sv, uint32_t id, f3 C, f3 o, f3 d, float t)
+// alpha >= AlphaCutoff.  Out of line (plain pointers, nothing of the kernel's argument structs): a rare path that the traversal loops
+// of every textured kernel would otherwise carry several inlined copies of -- those kernels are bound by their code size as it is.
+__device__ __attribute__((noinline)) inline bool crossing_is_opaque_ptr(const float4* __restrict__ mats, const uint32_t* __restrict__ tex_maps, const TexView* __restrict__ tex,
+                                                                        const float4* __restrict__ rot, uint32_t id, f3 C, f3 o, f3 d, float t)
 {
-    const float base_alpha = sv.mats[id * 4 + 0].w, cutoff = sv.mats[id * 4 + 3].y;
-    const uint32_t map = sv.tex_maps[(size_t)id * 8u + kMapBaseColor];
+    const float base_alpha = mats[id * 4 + 0].w, cutoff = mats[id * 4 + 3].y;
+    const uint32_t map = tex_maps[(size_t)id * 8u + kMapBaseColor];
     const f3 N = normalize(mad(t, d, o) - C);  // the hit frame's normal
     float4 q;
     f3 n_mesh;
-    const f2 uv = hit_uv(sv, id, N, q, n_mesh);
+    const f2 uv = hit_uv_rot(rot, id, N, q, n_mesh);
     float s[4];
-    sample_bilinear(sv.tex[map], uv, s);
+    sample_bilinear(tex[map], uv, s);
     return base_alpha * s[3] >= cutoff;
+}
+__device__ __forceinline__ bool crossing_is_opaque(const SceneView& sv, uint32_t id, f3 C, f3 o, f3 d, float t)
+{
+    return crossing_is_opaque_ptr(sv.mats, sv.tex_maps, sv.tex, sv.rot, id, C, o, d, t);
 }
 
 // A sphere test succeeded at t for the leaf with flagged id `idf` whose class bits are set (rare): does the sphere offer an
@@ -509,10 +516,12 @@ __device__ __forceinline__ HitMaterial hit_material(const SceneView& sv, uint32_
     f3 base = load3(m0), emissive_color = make_f3(m1.y, m1.z, m1.w);
     float metallic = m2.x, roughness = m2.y, transmission_m = m2.w;
     f3 Ns = r.hf.front ? r.hf.N : -r.hf.N;  // HitInfo.hlsli:60-64
-    if (kTex && sv.tex_maps) {
+    // (bit 31 of the device copy's AlphaMode word = "this sphere has texture maps", set by pt_set_textures: an untextured sphere in a textured
+    // scene -- almost every hit of the demo -- costs no look-up of its map table, which would sit on the dependent chain of every bounce)
+    if (kTex && (as_uint(m3.x) & kMaterialHasMaps) != 0u) {
         const uint4* mp = reinterpret_cast<const uint4*>(sv.tex_maps + (size_t)id * 8u);
         const uint4 ma = mp[0], mb = mp[1];
-        if (mb.w) {  // this sphere has at least one texture map
+        {
             const uint32_t maps[kMapCount] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z };
             float4 q;
             f3 n_mesh;
