@@ -171,7 +171,7 @@ def main():
     if args.animate:
         if args.scene != "demo":
             raise SystemExit("--animate is defined for the demo scene")
-        n_anim = 2 * args.steps + args.warmup + 8
+        n_anim = 2 * args.steps + args.warmup + 64  # (timed region, event-bracketed region, the one-frame-at-a-time frames)
         anim = [host.scene_at_time(0, k / 60.0) for k in range(n_anim)]  # host-side Tick (MyScene::SetTime), precomputed
 
     def step(k):

@@ -58,6 +58,12 @@ def main():
             if per(name) is not None:
                 e[name.lower() + "_per_launch"] = per(name)
         out["kernels"][k] = e
+    # frames of a pass = launches of the kernel every frame starts with (bench.py renders more frames than its --steps: warm-up, the
+    # event-bracketed region, the one-frame-at-a-time frames), so the count comes from the trace, not from the command line
+    for first in ("bounce<primary>", "primary"):
+        if first in out["kernels"]:
+            out["frames_per_pass"] = out["kernels"][first]["launches"]
+            break
     json.dump(out, open(os.path.join(d, "counters.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

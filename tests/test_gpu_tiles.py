@@ -277,3 +277,39 @@ def test_bench_control_flow_with_two_ranks():
     tx = d["config"]["tile_exchange"]
     assert tx["autotune"]["chosen"] in tx["autotune"]["candidates"] and len(tx["autotune"]["seconds"]) == len(tx["autotune"]["candidates"])
     assert "rehearsal" in d["config"] and d["roofline"]["bound"] == "hbm"
+
+
+def test_bench_on_two_gpus_over_rccl():
+    """The real N > 1 run (needs a box with at least two GPUs; the build's own boxes have one, so this is skipped there): bench.py with two ranks
+    over RCCL, measured through torch.distributed.gather, then -- after the result line -- the C-ABI's own exchange (pt_comm_init / pt_gather)
+    brought up, compared bit for bit with the frames of the torch path and timed (bench.py cabi_post_check); and the same run with the C-ABI
+    exchange as the measured path."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import pytest
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k, gather in enumerate(("torch", "cabi")):
+        port = 29700 + (os.getpid() + k) % 200
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--no-cpu-baseline", "--no-roofline", "--gather", gather],
+                           cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        d = json.loads(lines[0])
+        tx = d["config"]["tile_exchange"]
+        assert d["n_gpus"] == 2 and tx["ranks_seen"] == 2 and d["value"] > 0
+        assert sum(r[1] for r in tx["rays_and_pixels_per_rank"]) == 1920 * 1080 * 12  # every pixel of every frame rendered exactly once
+        if gather == "torch":
+            check = [ln for ln in p.stderr.splitlines() if ln.startswith("[bench] cabi_check: ")]
+            assert len(check) == 1, p.stderr[-3000:]
+            c = json.loads(check[0][len("[bench] cabi_check: "):])
+            assert c["ok"] and c["frames_bit_identical_to_torch_gather"], c
+        else:
+            assert "pt_gather" in tx["gather"]
