@@ -39,6 +39,11 @@ def random_scene(dxrs, rng, n):
     emit = rng.random(n) < 0.25
     m["EmissiveStrength"][emit] = rng.uniform(0.5, 50.0, emit.sum())
     m["EmissiveColor"][emit] = rng.random((emit.sum(), 3))
+    if rng.random() < 0.5:  # alpha-tested hits (spec S10) in half of the scenes: Mask / Blend spheres above, at and below their cut-off
+        a = rng.random(n) < 0.3
+        m["AlphaMode"][a] = rng.choice([1, 2], a.sum())
+        m["BaseColor"][a, 3] = rng.choice([0.0, 0.3, 0.5, 0.9, 1.0], a.sum())
+        m["AlphaCutoff"][a] = rng.choice([0.5, 0.25, 1.0], a.sum())
     return s, m
 
 
