@@ -42,7 +42,7 @@ struct EventPair {
 struct Knobs {
     int split = -1, traverse_blocks_per_cu = -1, fused_threads = -1, no_adaptive_grid = -1, shade_blocks_per_cu = -1, tail_threshold = -1,
         tail_blocks_per_cu = -1, loop_threads = -1, inline2_min_slots = -1, tail_after = -1, seg = -1, loop_use_tail = -1, fuse_loop = -1,
-        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1, lane_priority = -1, fused_refit = -1, primary_cache = -1;
+        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1, lane_priority = -1, fused_refit = -1;
 };
 
 // Per-frame-in-flight state (see PtContext::lanes).
@@ -510,7 +510,7 @@ Knobs read_knobs()
     k.inline2_min_slots = env_knob("PT_INLINE2_MIN_SLOTS"); k.tail_after = env_knob("PT_TAIL_AFTER"); k.seg = env_knob("PT_SEG");
     k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.lane_priority = env_knob("PT_LANE_PRIORITY"); k.fused_refit = env_knob("PT_FUSED_REFIT"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
     k.dyn_blocks_per_cu = env_knob("PT_DYN_BLOCKS_PER_CU"); k.debug_counts = std::getenv("PT_DEBUG_COUNTS") ? 1 : -1; k.sah = env_knob("PT_SAH");
-    k.sah_max_spheres = env_knob("PT_SAH_MAX_SPHERES"); k.beams = env_knob("PT_BEAMS"); k.wide = env_knob("PT_WIDE"); k.descent = env_knob("PT_DESCENT"); k.roctx = env_knob("PT_ROCTX"); k.primary_cache = env_knob("PT_PRIMARY_CACHE");
+    k.sah_max_spheres = env_knob("PT_SAH_MAX_SPHERES"); k.beams = env_knob("PT_BEAMS"); k.wide = env_knob("PT_WIDE"); k.descent = env_knob("PT_DESCENT"); k.roctx = env_knob("PT_ROCTX");
     return k;
 }
 
@@ -894,9 +894,9 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
             const bool fuse = seg && knob_or(c->knobs.fuse_loop, pm.n_slots < 400000u ? 1u : 0u) != 0;
             if (seg) { fc_seg.seg_counts = L.d_seg_counts; fc_seg.n_segs = primary_grid; fc_seg.seg_cap = seg_cap; fc_seg.fuse_loop = fuse ? 1u : 0u; }
             // spp > 1 with a separate looping pass over an untextured scene: the primary pass leaves each pixel's primary-hit record for the
-            // samples the looping pass regenerates (Scratch::primary_cache; PT_PRIMARY_CACHE=0 switches it off, for A/B runs)
+            // samples the looping pass regenerates, and where it writes the pixel (Scratch::primary_cache)
             Scratch scratch = L.scratch;
-            if (!(loop_is_main && !fuse && !sv.tex_maps && knob_or(c->knobs.primary_cache, 1u) != 0)) scratch.primary_cache = nullptr;
+            if (sv.tex_maps || fuse || spp == 1) scratch.primary_cache = nullptr;  // (the untextured looping kernel of spp > 1 frames relies on the records)
             // pass 0 generates + traces the primaries and shades them into queue 1; pass k >= 1 consumes queue k
             for (size_t k = 0;; k++) {
                 const RayQueue& qin = L.q[k & 1];

@@ -599,7 +599,7 @@ struct NoTrace {
 // primary surface, sharing its material / BSDF evaluation; `trace` casts the shadow ray, `di_rays` counts it.  With kDI = false
 // and fp.di_enabled the estimate is read from scratch.di (written by a kDI pass or, in the split schedule, by di_kernel).
 // kCacheMode (kMulti, untextured kernels; Scratch::primary_cache): 1 = the primary pass stores what the first shading of the primary
-// surface computed; 2 = the looping pass restarts a pixel's next sample from that record instead of recomputing the primary ray, the
+// surface computed (plus where the pixel is written); 2 = the looping pass restarts a pixel's next sample from that record instead of recomputing the primary ray, the
 // hit frame and the lobe weights (~250 of the ~1100 instructions of a full shading step, once per sample: all samples of a pixel share
 // their primary hit, Raytracing.hlsl:193-198).  The cached values are the ones the full path computes, bit for bit.
 // kMerge (the looping pass at spp > 1): ONE pass through the surface-shading code per call.  The plain form shades the traced hit,
@@ -633,7 +633,7 @@ __device__ __forceinline__ int shade_step_ex(const SceneView& sv, const PixelMap
         if (kTex && sv.env_tex != kNoTexture)
             env = sv.env_cube ? environment_cube(sv.tex + sv.env_tex, sv.env_xf, ps.d) : environment_texture(sv.tex[sv.env_tex], sv.env_xf, ps.d);
         else env = environment_color(sv.env[0], sv.env[1], sv.env[2], sv.env[3], ps.d);
-        if (ps.bounce == 0) {  // primary miss: pixel = environment (GBufferGeneration.hlsl:223-227; Raytracing.hlsl:249-252)
+        if (!kMerge && ps.bounce == 0) {  // primary miss: pixel = environment (GBufferGeneration.hlsl:223-227; Raytracing.hlsl:249-252); the looping pass only sees paths with a primary hit
             out[slot_to_pixel(pm, slot).out_index] = make_float4(env.x, env.y, env.z, 1.0f);
             return true;
         }
@@ -701,7 +701,7 @@ __device__ __forceinline__ int shade_step_ex(const SceneView& sv, const PixelMap
                 float4* rec = scratch.primary_cache + (size_t)slot * 3u;
                 rec[0] = make_float4(hf.N.x, hf.N.y, hf.N.z, hf.offset);
                 rec[1] = make_float4(w[0], w[1], w[2], as_float(id));
-                rec[2] = make_float4(ps.d.x, ps.d.y, ps.d.z, 0.f);
+                rec[2] = make_float4(ps.d.x, ps.d.y, ps.d.z, as_float(slot_to_pixel(pm, slot).out_index));  // (where the pixel is written: the looping pass needs no slot -> pixel mapping)
             }
         }
         float rnd[4];
@@ -750,7 +750,8 @@ __device__ __forceinline__ int shade_step_ex(const SceneView& sv, const PixelMap
                 if (kDI && di_have) res = res + di_val;
                 else { const float4 di = scratch.di[slot]; res = res + load3(di); }
             }
-            out[slot_to_pixel(pm, slot).out_index] = make_float4(res.x, res.y, res.z, 1.0f);
+            const uint32_t out_index = kCacheMode == 2 ? as_uint(scratch.primary_cache[(size_t)slot * 3u + 2u].w) : slot_to_pixel(pm, slot).out_index;
+            out[out_index] = make_float4(res.x, res.y, res.z, 1.0f);
             return true;
         }
         scratch.radiance[slot] = make_float4(total.x, total.y, total.z, 0.f);
@@ -759,7 +760,7 @@ __device__ __forceinline__ int shade_step_ex(const SceneView& sv, const PixelMap
 
     // regenerate: every sample restarts from the same primary ray / primary hit (:193-198)
     auto regenerate = [&]() {
-        if (kCacheMode == 2 && scratch.primary_cache) {
+        if (kCacheMode == 2) {  // (the host hands kernels of this mode the records: render_common)
             const float4* rec = scratch.primary_cache + (size_t)slot * 3u;
             rc0 = rec[0]; rc1 = rec[1];
             const float4 rc2 = rec[2];
