@@ -104,6 +104,12 @@ __device__ __forceinline__ int stack_decode(uint32_t v) { return (int)v; }
 
 constexpr int kTraversalDone = (int)0x80000000;  // not a valid leaf code (leaf codes are >= -2^30)
 
+// fminf / fmaxf against a value the compiler cannot prove quiet (tmin and the running best cross basic blocks) cost an extra
+// v_max x, x per operand and per node visit.  Neither is ever a signalling NaN, so the slab test names the instruction itself:
+// v_min_f32 / v_max_f32 return the other operand for a quiet NaN exactly as fminf / fmaxf do (DESIGN.md, "Conservativeness").  Measured: C2 -0.8 %.
+__device__ __forceinline__ float raw_minf(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float raw_maxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 // One visit of a 4-wide node (pt_lbvh_gpu.hip collapse4_kernel: the grandchildren of an even-depth binary node, their boxes as
 // 8-bit offsets on a per-node power-of-two grid; global-memory scenes): four slab tests from ONE 64-byte record, the hit
 // children ordered near to far by a 5-exchange network, the nearest descended into, the others pushed far-first.  Half the
@@ -125,8 +131,8 @@ __device__ __forceinline__ void wide_visit(const float4* __restrict__ wide, int&
         const float ax = pt_fma((float)((w1.x >> (8 * c)) & 0xFFu), sx, bx0), bx = pt_fma((float)((w1.w >> (8 * c)) & 0xFFu), sx, bx0);   \
         const float ay = pt_fma((float)((w1.y >> (8 * c)) & 0xFFu), sy, by0), by = pt_fma((float)((w2.x >> (8 * c)) & 0xFFu), sy, by0);   \
         const float az = pt_fma((float)((w1.z >> (8 * c)) & 0xFFu), sz, bz0), bz = pt_fma((float)((w2.y >> (8 * c)) & 0xFFu), sz, bz0);   \
-        const float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));                      \
-        const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best));                       \
+        const float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), raw_maxf(fminf(az, bz), tmin));                   \
+        const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), raw_minf(fmaxf(az, bz), best));                    \
         tn[c] = (tnear <= tfar && ref[c] != kTraversalDone) ? tnear : kInf;                                             \
     }
     PT_WIDE_CHILD(0) PT_WIDE_CHILD(1) PT_WIDE_CHILD(2) PT_WIDE_CHILD(3)
@@ -207,11 +213,6 @@ __device__ __forceinline__ bool alpha_candidate(const SceneView& sv, uint32_t id
     }
 }
 
-// fminf / fmaxf against a value the compiler cannot prove quiet (tmin and the running best cross basic blocks) cost an extra
-// v_max x, x per operand and per node visit.  Neither is ever a signalling NaN, so the slab test names the instruction itself:
-// v_min_f32 / v_max_f32 return the other operand for a quiet NaN exactly as fminf / fmaxf do (DESIGN.md, "Conservativeness").  Measured: C2 -0.8 %.
-__device__ __forceinline__ float raw_minf(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float raw_maxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // Closest hit over the LBVH ("while-while" traversal: descend internal nodes until every lane of the wave holds a
 // leaf or has finished, then run the sphere tests together).  nodes/sph/ids may live in LDS or global memory (the
 // address space is inferred after inlining).  stack: per-lane stack, entry e of lane l at stack[e * stride + l].
@@ -852,6 +853,22 @@ __device__ __forceinline__ void store_path(const RayQueue& q, uint32_t j, const 
 // 64 KB default limit counts both, so the opt-in for more is taken this much earlier
 constexpr uint32_t kStaticLdsMargin = (kMaxSegs + 64u) * 4u;
 
+// Cold kernel arguments.  A by-value kernel argument is loaded into SGPRs at the kernel's entry and stays there: with ~120 dwords of
+// arguments and 100 SGPRs, the camera and the pixel map -- needed once per batch, to generate the primary rays -- lived in VGPR lanes
+// and came back through ~70 v_readlane per batch (VALU issue slots, in a VALU-bound kernel).  cold_arg re-reads such an argument from the
+// kernarg segment where it is used (s_load, scalar cache): the laundered pointer keeps the loads inside the loop.
+// The leading arguments of bounce_kernel, as the kernarg segment lays them out (in order, each at its natural alignment = a C struct):
+struct BounceArgHead { SceneView sv; PixelMap pm; FrameParams fp; };
+template <typename T>
+__device__ __forceinline__ T cold_arg(uint32_t offset)
+{
+    const __attribute__((address_space(4))) char* p = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    T v;
+    __builtin_memcpy(&v, p + offset, sizeof(T));
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------ fused bounce
 // trace + shade in one kernel (DESIGN.md "Kernels"): a lane obtains a ray (kPrimary: generated from its pixel; else read
 // from the input queue), traces it, and runs one shade_step.  kLoop = false: survivors are compacted into the output
@@ -988,15 +1005,17 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
             bool live = true;
             float tmin = 0.0f, tmax = kInf;
             if (kPrimary) {
-                const PixelRef pr = slot_to_pixel(pm, i);
+                const PixelMap pm_c = cold_arg<PixelMap>(offsetof(BounceArgHead, pm));
+                const PixelRef pr = slot_to_pixel(pm_c, i);
                 live = pr.valid;
                 ps.slot = i; ps.bounce = 0; ps.sample = 0; ps.dirty = false; ps.via_t = false; ps.rng = 0;
                 ps.T = make_f3(1.f, 1.f, 1.f);
                 ps.o = make_f3(0.f, 0.f, 0.f); ps.d = make_f3(0.f, 0.f, 1.f);
                 if (live) {
-                    primary_ray(fp.cam, pr.px, pr.py, ps.o, ps.d, tmin, tmax);
+                    const CameraParams cam_c = cold_arg<CameraParams>(offsetof(BounceArgHead, fp) + offsetof(FrameParams, cam));
+                    primary_ray(cam_c, pr.px, pr.py, ps.o, ps.d, tmin, tmax);
                     ps.rng = rng_init(pr.px, pr.py, fp.frame_index);
-                } else if (pm.mode == 1) {
+                } else if (pm_c.mode == 1) {
                     out[pr.out_index] = make_float4(0.f, 0.f, 0.f, 0.f);  // padding pixel of an edge tile
                 }
             } else if (seg_in) {
