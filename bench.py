@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--prewarm", type=int, default=-1,
+                    help="untimed frames rendered before the --warmup frames, to bring a cold GPU to its running clocks (the driver's run is ~2 ms of GPU "
+                         "work in all); -1 = 256 for frames up to 4 M pixel-samples, 8 beyond; 0 = none; reported as config.prewarm_frames")
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--bounces", type=int, default=BOUNCES)
@@ -217,6 +220,18 @@ def main():
             # (five candidates x two runs of two batches: a few dozen frames, small against the measurement itself)
             n_tune = 2 * ex.batch
             ex.autotune(lambda e: run_steps(0, n_tune), sync_all, candidates=[1, 2, 4, 8, 0], log=tune_log)
+    # Untimed, before the warm-up proper: a freshly leased GPU takes tens of milliseconds of work to reach the state a renderer runs in
+    # (tools/experiments/warm20.sh: the same 20 timed frames take 0.091-0.100 ms each after 5 frames, 0.087-0.092 after 3000), and the
+    # contract's region is 20 frames after 5.  The same frames as the warm-up, over and over; every rank renders the same number.
+    prewarm = 0 if rehearsal else args.prewarm if args.prewarm >= 0 else (256 if w * h * args.spp <= 4200000 else 8)  # (a rehearsal's timings mean nothing)
+    if prewarm:
+        sync_all()
+        n_cycle = max(1, min(args.warmup, 32))
+        for k in range(prewarm):
+            step(k % n_cycle)
+        if tiled:
+            ex.finish()
+        sync_all()
     run_steps(0, args.warmup)
     r.totals(reset=True)
     elapsed = run_steps(args.warmup, args.steps)
@@ -292,6 +307,7 @@ def main():
                                       "ranks_seen": world, "rays_and_pixels_per_rank": per_rank}} if tiled else {}),
                 **({"rehearsal": "PT_BENCH_REHEARSAL=1: all ranks on ONE GPU over gloo -- control-flow rehearsal, not a measurement"} if rehearsal else {}),
                 "frames_in_flight": args.frames_in_flight,
+                "prewarm_frames": prewarm,
                 "one_frame_at_a_time": serial,
                 "animated": bool(args.animate),
                 "moving_camera": bool(args.moving_camera),

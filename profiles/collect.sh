@@ -11,7 +11,7 @@ R=$(pwd)
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 LONG="--steps ${PT_PROFILE_STEPS:-300} --warmup ${PT_PROFILE_WARMUP:-30}"
-SHORT="--steps ${PT_PROFILE_PMC_STEPS:-20} --warmup 2 --no-cpu-baseline --no-roofline --frames-in-flight 1"
+SHORT="--steps ${PT_PROFILE_PMC_STEPS:-20} --warmup 2 --prewarm 0 --no-cpu-baseline --no-roofline --frames-in-flight 1"
 python3 bench.py $LONG "$@" > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/bench_20_steps.json 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
