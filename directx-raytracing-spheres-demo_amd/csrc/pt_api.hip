@@ -42,7 +42,7 @@ struct EventPair {
 struct Knobs {
     int split = -1, traverse_blocks_per_cu = -1, fused_threads = -1, no_adaptive_grid = -1, shade_blocks_per_cu = -1, tail_threshold = -1,
         tail_blocks_per_cu = -1, loop_threads = -1, inline2_min_slots = -1, tail_after = -1, seg = -1, loop_use_tail = -1, fuse_loop = -1,
-        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1, lane_priority = -1, fused_refit = -1;
+        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1, lane_priority = -1, fused_refit = -1, beam_reach = -1, beam_max_slack_pct = -1;
 };
 
 // Per-frame-in-flight state (see PtContext::lanes).
@@ -168,20 +168,34 @@ struct PtContext {
     uint32_t tot_beam_frames = 0;  // frames since the last reset whose primary pass used the primary-beam lists
 
     // Primary beams (DESIGN.md "Primary beams"): per-8x8-block candidate sphere lists for the primary pass.  They depend on the
-    // camera pose, the frame geometry and the scene -- not on the frame index or the jitter (the beams are a pixel wider than
-    // the blocks) -- so they are built when a view RESTS: the second consecutive frame with the same key starts the build on
-    // a side stream, the frames after that use the lists; a moving camera or scene never pays for them.
-    struct BeamCache {
+    // camera's orientation, the frame geometry and the scene, and on the camera's POSITION up to the slack they were built with
+    // (Beam::slack) -- not on the frame index or the jitter (the beams are a pixel wider than the blocks).  A view that RESTS gets
+    // lists with no slack on its second frame; a camera that moves without turning gets lists centred a few frames ahead of it
+    // with a slack of a few frames' travel, rebuilt on a side stream while the frames use the previous ones -- a frame never waits
+    // for a build of the moving kind: it takes the newest lists that are ready and hold for its pose, or traverses per ray.
+    struct BeamLists {
         uint32_t* d_lists = nullptr;   // n_blocks records of 16 dwords
         size_t cap_blocks = 0;
-        std::vector<uint32_t> key;     // key of the lists in d_lists (valid once ev_ready has completed); empty = none
-        std::vector<uint32_t> last_key;  // key of the previous render call
-        hipStream_t stream = nullptr;
+        std::vector<uint32_t> key;     // orientation, frame geometry, scene generation of the lists in d_lists; empty = none
+        float pos[3] = { 0, 0, 0 };    // the camera position they were built around ...
+        float slack = 0.0f;            // ... and how far from it they hold
         hipEvent_t ev_ready = nullptr;   // the build has finished
+        bool building = false;         // launched, ev_ready not yet seen complete
+        bool used = false;             // read by a frame since the build (a rebuild must wait for the lanes)
+        uint64_t first_call = 0;       // the first render call whose frame may read them (BeamCache::calls)
+    };
+    struct BeamCache {
+        BeamLists buf[2];
+        int cur = 0;                     // the lists frames use; the other buffer is the one a build goes to
+        uint64_t calls = 0;              // render calls that consulted the cache
+        std::vector<uint32_t> last_key;  // key / position of the previous render call
+        float last_pos[3] = { 0, 0, 0 };
+        hipStream_t stream = nullptr;      // side stream (the builds of resting views)
         hipEvent_t ev_last_use = nullptr;  // scratch event of a rebuild (orders it after the lanes' frames in flight)
-        bool used = false;
+        struct { bool want = false; BeamLists* dst = nullptr; float centre[3] = { 0, 0, 0 }; float slack = 0.0f; std::vector<uint32_t> key; uint64_t first_call = 0; } pending;  // a build to queue behind this frame
     } beam;
     uint64_t scene_gen = 0;  // bumped by everything that changes what a ray can hit
+    float min_radius = 0.0f;  // smallest sphere of the scene set by pt_set_scene (bounds the slack of a moving camera's beam lists)
 
     // multi-GPU exchange (pt_comm_init / pt_gather): the RCCL communicator of this rank
     ncclComm_t comm = nullptr;
@@ -508,7 +522,7 @@ Knobs read_knobs()
     k.no_adaptive_grid = std::getenv("PT_NO_ADAPTIVE_GRID") ? 1 : -1; k.shade_blocks_per_cu = env_knob("PT_SHADE_BLOCKS_PER_CU");
     k.tail_threshold = env_knob("PT_TAIL_THRESHOLD"); k.tail_blocks_per_cu = env_knob("PT_TAIL_BLOCKS_PER_CU"); k.loop_threads = env_knob("PT_LOOP_THREADS");
     k.inline2_min_slots = env_knob("PT_INLINE2_MIN_SLOTS"); k.tail_after = env_knob("PT_TAIL_AFTER"); k.seg = env_knob("PT_SEG");
-    k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.lane_priority = env_knob("PT_LANE_PRIORITY"); k.fused_refit = env_knob("PT_FUSED_REFIT"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
+    k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.beam_reach = env_knob("PT_BEAM_REACH"); k.beam_max_slack_pct = env_knob("PT_BEAM_MAX_SLACK_PCT"); k.lane_priority = env_knob("PT_LANE_PRIORITY"); k.fused_refit = env_knob("PT_FUSED_REFIT"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
     k.dyn_blocks_per_cu = env_knob("PT_DYN_BLOCKS_PER_CU"); k.debug_counts = std::getenv("PT_DEBUG_COUNTS") ? 1 : -1; k.sah = env_knob("PT_SAH");
     k.sah_max_spheres = env_knob("PT_SAH_MAX_SPHERES"); k.beams = env_knob("PT_BEAMS"); k.wide = env_knob("PT_WIDE"); k.descent = env_knob("PT_DESCENT"); k.roctx = env_knob("PT_ROCTX");
     return k;
@@ -578,54 +592,135 @@ void sum_events(PtContext* c, size_t begin, size_t end, PtStats* stats)
     }
 }
 
-// Primary-beam cache (PtContext::BeamCache).  *lists = the cached lists if they were built for this frame's view, else null.
-// The view's key: camera pose (not the jitter: the beams are a pixel wider than their blocks), frame geometry, scene generation.
-PtStatus beam_cache_lookup(PtContext* c, const PixelMap& pm, const uint32_t** lists)
+// Launches the build of primary-beam lists into `dst` (centre, slack: Beam), on stream `on` or, if null, on the cache's side stream.
+static PtStatus beam_build(PtContext* c, const PixelMap& pm, PtContext::BeamLists* dst, const float centre[3], float slack, std::vector<uint32_t> key, hipStream_t on)
+{
+    auto& B = c->beam;
+    if (!B.ev_last_use) PT_HIP(c, hipEventCreateWithFlags(&B.ev_last_use, hipEventDisableTiming));
+    if (!on) {
+        if (!B.stream) PT_HIP(c, hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+        on = B.stream;
+    }
+    if (!dst->ev_ready) PT_HIP(c, hipEventCreateWithFlags(&dst->ev_ready, hipEventDisableTiming));
+    const size_t n_blocks = pm.n_slots >> 6;
+    if (n_blocks > dst->cap_blocks) {
+        PT_HIP(c, sync_all(c));  // frames in flight may read the old lists
+        if (B.stream) PT_HIP(c, hipStreamSynchronize(B.stream));
+        free_dev(dst->d_lists);
+        dst->cap_blocks = 0;
+        PT_HIP(c, hipMalloc(&dst->d_lists, n_blocks * 16u * sizeof(uint32_t)));
+        dst->cap_blocks = n_blocks;
+        dst->used = false;
+    }
+    // an earlier build into this buffer may still run (on another lane's stream), and the frames in flight may still read the buffer's
+    // previous lists: the build waits for both (device-side waits only)
+    if (dst->building) PT_HIP(c, hipStreamWaitEvent(on, dst->ev_ready, 0));
+    if (dst->used)
+        for (uint32_t i = 0; i < c->n_lanes; i++) {
+            if (c->lanes[i].stream == on) continue;  // (in order behind them anyway)
+            PT_HIP(c, hipEventRecord(B.ev_last_use, c->lanes[i].stream));
+            PT_HIP(c, hipStreamWaitEvent(on, B.ev_last_use, 0));
+        }
+    FrameParams fp = make_frame_params(c);
+    fp.cam.Position = make_f3(centre[0], centre[1], centre[2]);
+    PT_HIP(c, launch_beams(make_scene_view(c), pm, fp, slack, dst->d_lists, on));
+    PT_HIP(c, hipEventRecord(dst->ev_ready, on));
+    dst->key = std::move(key);
+    std::memcpy(dst->pos, centre, 12);
+    dst->slack = slack;
+    dst->building = true;
+    dst->used = false;
+    return PT_OK;  // this frame still traverses (or uses the lists it has); later ones find the new lists
+}
+
+// Primary-beam cache (PtContext::BeamCache).  *lists = lists that hold for this frame's view, else null; *wait = an event the frame must
+// wait for before it reads them (the first frames of a resting view), or null.
+PtStatus beam_cache_lookup(PtContext* c, const PixelMap& pm, const uint32_t** lists, hipEvent_t* wait)
 {
     *lists = nullptr;
+    *wait = nullptr;
     auto& B = c->beam;
+    B.pending.want = false;
     std::vector<uint32_t> key;
     key.reserve(32);
     auto put_f = [&](const float* v, int n) { for (int i = 0; i < n; i++) { uint32_t u; std::memcpy(&u, v + i, 4); key.push_back(u); } };
-    put_f(c->cam.Position, 3); put_f(c->cam.RightDirection, 3); put_f(c->cam.UpDirection, 3); put_f(c->cam.ForwardDirection, 3);
+    put_f(c->cam.RightDirection, 3); put_f(c->cam.UpDirection, 3); put_f(c->cam.ForwardDirection, 3);
     for (uint32_t v : { pm.mode, pm.img_w, pm.img_h, pm.rx, pm.ry, pm.rw, pm.rh, pm.ts, pm.first, pm.run, pm.stride, pm.n_slots,
                         (uint32_t)c->scene_gen, (uint32_t)(c->scene_gen >> 32) }) key.push_back(v);
-    if (!B.key.empty() && key == B.key) {
-        *lists = B.d_lists;
-        B.used = true;
-        B.last_key = std::move(key);
+    const float* pos = c->cam.Position;
+    auto dist = [](const float* a, const float* b) {
+        const double dx = (double)a[0] - b[0], dy = (double)a[1] - b[1], dz = (double)a[2] - b[2];
+        return std::sqrt(dx * dx + dy * dy + dz * dz);
+    };
+    // (the kernel's plane tests carry their own rounding margin; the host's distance is exact to double rounding, hence the 1e-4)
+    const uint64_t call = ++B.calls;
+    auto holds = [&](const PtContext::BeamLists& b) { return !b.key.empty() && b.key == key && call >= b.first_call && (b.slack == 0.0f ? std::memcmp(b.pos, pos, 12) == 0 : dist(b.pos, pos) <= (double)b.slack * (1.0 - 1e-4)); };
+    const bool same_orientation = key == B.last_key;
+    const double step = same_orientation ? dist(pos, B.last_pos) : 0.0;  // the camera's travel since the previous call
+    const bool finite_pos = std::isfinite(pos[0]) && std::isfinite(pos[1]) && std::isfinite(pos[2]);
+    const float prev[3] = { B.last_pos[0], B.last_pos[1], B.last_pos[2] };
+    B.last_key = key;
+    std::memcpy(B.last_pos, pos, 12);
+    PtContext::BeamLists* cur = &B.buf[B.cur];
+    PtContext::BeamLists* nxt = &B.buf[B.cur ^ 1];
+    for (auto& b : B.buf)
+        if (b.building) {
+            if (hipEventQuery(b.ev_ready) == hipSuccess) b.building = false;
+            else (void)hipGetLastError();
+        }
+    // Lists in use first; else the other buffer's, if they hold (the newer build).  A build the host has not seen finish is waited for ON THE
+    // DEVICE: the host runs many frames ahead of the GPU, so "finished" at call time means little -- what counts is the order of the streams.
+    if (holds(*nxt) && (!holds(*cur) || (nxt->slack == 0.0f && cur->slack > 0.0f && !nxt->building))) {  // (or: exact lists for a camera that has stopped, once they are there)
+        B.cur ^= 1;
+        std::swap(cur, nxt);
+    }
+    if (holds(*cur)) {
+        *lists = cur->d_lists;
+        cur->used = true;
+        if (cur->building) *wait = cur->ev_ready;
+    }
+    // Start a build?  Only for an orientation that has lasted two calls (a turning camera never pays), into the buffer frames do not use.
+    if (!same_orientation || !finite_pos) return PT_OK;
+    float centre[3] = { pos[0], pos[1], pos[2] };
+    float slack = 0.0f;
+    if (step == 0.0) {
+        if (*lists && cur->slack == 0.0f) return PT_OK;  // resting, and served by exact lists (a camera that has just stopped swaps its widened ones for exact ones)
+        if (holds(*nxt) && nxt->slack == 0.0f) return PT_OK;  // (already being built)
+    } else {
+        // Moving.  A build queued behind THIS frame on its lane is in stream order before the frame `a` calls later on the same lane, and
+        // the frames of the other lanes from then on wait for its event -- by then it has usually finished, a lone 55-us kernel behind a frame
+        // that ended a frame or two earlier.  So the lists are made for the frames a .. a + reach calls from now: centred on the position
+        // extrapolated to the middle of that span, with half the span's travel (+ 2 frames' for a changing speed) as slack, and renewed
+        // when the lists in use will have run out a + 1 calls from now.
+        const uint32_t reach = knob_or(c->knobs.beam_reach, 32u);
+        if (reach == 0u) return PT_OK;  // (PT_BEAM_REACH=0: lists for resting views only)
+        const double a = (double)c->n_lanes;
+        const double v[3] = { (double)pos[0] - prev[0], (double)pos[1] - prev[1], (double)pos[2] - prev[2] };
+        auto ahead = [&](double f, float out[3]) { for (int i = 0; i < 3; i++) out[i] = (float)((double)pos[i] + f * v[i]); };
+        float soon[3];
+        ahead(a + 1.0, soon);
+        auto covers = [&](const PtContext::BeamLists& b, const float* q) { return !b.key.empty() && b.key == key && b.slack > 0.0f && call + c->n_lanes + 1 >= b.first_call && dist(b.pos, q) <= (double)b.slack * (1.0 - 1e-4); };
+        if (covers(*cur, soon) || covers(*nxt, soon)) return PT_OK;
+        // The slack widens every pyramid by an absolute distance, so it must stay small against the spheres or the lists overflow: at most
+        // the smallest radius.  A faster camera gets lists for fewer frames; one that jumps (fewer than 4 frames' worth) gets none until it rests.
+        double span = (double)reach;
+        const double max_slack = (double)c->min_radius * 0.01 * (double)knob_or(c->knobs.beam_max_slack_pct, 100u);
+        if ((0.5 * span + 2.0) * step > max_slack) span = 2.0 * (std::floor(max_slack / step) - 2.0);
+        if (!(span >= 4.0)) return PT_OK;
+        ahead(a + 0.5 * span, centre);
+        slack = (float)((0.5 * span + 2.0) * step);
+        if (!(slack > 0.0f) || !std::isfinite(slack) || !std::isfinite(centre[0]) || !std::isfinite(centre[1]) || !std::isfinite(centre[2])) return PT_OK;
+    }
+    PtContext::BeamLists* dst = *lists ? nxt : cur;  // nothing usable in `cur`: build there (no swap needed later)
+    if (slack > 0.0f) {
+        // a moving camera's lists: queued by render_common behind this frame's kernels, on its lane
+        // (not for the frames before that: they would wait for this whole frame plus the build)
+        B.pending.want = true; B.pending.dst = dst; B.pending.slack = slack; B.pending.key = std::move(key); B.pending.first_call = call + c->n_lanes;
+        std::memcpy(B.pending.centre, centre, 12);
         return PT_OK;
     }
-    const bool rested = key == B.last_key;  // the second consecutive frame of this view: worth building for
-    B.last_key = key;
-    if (!rested) return PT_OK;
-    if (!B.stream) {
-        PT_HIP(c, hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
-        PT_HIP(c, hipEventCreateWithFlags(&B.ev_ready, hipEventDisableTiming));
-        PT_HIP(c, hipEventCreateWithFlags(&B.ev_last_use, hipEventDisableTiming));
-    }
-    const size_t n_blocks = pm.n_slots >> 6;
-    if (n_blocks > B.cap_blocks) {
-        PT_HIP(c, sync_all(c));  // frames in flight may read the old lists
-        PT_HIP(c, hipStreamSynchronize(B.stream));
-        free_dev(B.d_lists);
-        PT_HIP(c, hipMalloc(&B.d_lists, n_blocks * 16u * sizeof(uint32_t)));
-        B.cap_blocks = n_blocks;
-        B.used = false;
-    }
-    // the frames in flight may still read the previous lists: the build waits for every lane (device-side waits only; a
-    // rebuild happens once per resting view, so their cost does not matter)
-    if (B.used)
-        for (uint32_t i = 0; i < c->n_lanes; i++) {
-            PT_HIP(c, hipEventRecord(B.ev_last_use, c->lanes[i].stream));
-            PT_HIP(c, hipStreamWaitEvent(B.stream, B.ev_last_use, 0));
-        }
-    FrameParams fp = make_frame_params(c);
-    PT_HIP(c, launch_beams(make_scene_view(c), pm, fp, B.d_lists, B.stream));
-    PT_HIP(c, hipEventRecord(B.ev_ready, B.stream));
-    B.key = std::move(key);
-    B.used = false;
-    return PT_OK;  // this frame still traverses; the next ones of this view find the lists
+    dst->first_call = call + 1;
+    return beam_build(c, pm, dst, centre, slack, std::move(key), nullptr);  // a resting view's: on the side stream; the next frame waits for it, once
 }
 
 // Moving spheres (row N2).  Every lane owns a copy of what moves (spheres, Morton-ordered spheres, node boxes) and a pinned staging
@@ -754,18 +849,16 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     if (L.needs_refit && (st = refit_lane(c, L)) != PT_OK) return st;  // pt_update_spheres without pt_refit_accel: the frame refits by itself
     c->last_lane = c->next_lane;
     c->next_lane = (c->next_lane + 1) % c->n_lanes;
-    // Primary beams: use the cached candidate lists when this frame's view is the one they were built for; start a build
-    // (side stream) when the view has rested for two consecutive frames.  PT_BEAMS=0 switches them off, for A/B runs.
-    // (Building lists in front of EVERY frame of a moving view was measured, with the tree staged in LDS for the build: the
-    // animated C2 frame went from 0.099 to 0.117 ms -- the build lengthens the frame's dependent chain by more than the primary
-    // pass gains.  Resting views only.)
+    // Primary beams: use cached candidate lists that hold for this frame's view (beam_cache_lookup): exact ones for a view that has rested
+    // for two frames, ones with slack for a camera that moves without turning.  PT_BEAMS=0 switches them off, PT_BEAM_REACH=0 the moving
+    // kind, for A/B runs.  (Building lists in front of EVERY frame of a changing view was measured, with the tree staged in LDS for the
+    // build: the animated C2 frame went from 0.099 to 0.117 ms -- the build lengthens the frame's dependent chain by more than the
+    // primary pass gains.  Animated scenes get none.)
     const uint32_t* beam_lists = nullptr;
     if (!split && !L.scene_private && c->n_nodes > 0 && knob_or(c->knobs.beams, 1u) != 0 && std::fabs(c->cam.Jitter[0]) <= 0.5f && std::fabs(c->cam.Jitter[1]) <= 0.5f) {
-        if ((st = beam_cache_lookup(c, pm, &beam_lists)) != PT_OK) return st;
-        if (beam_lists && hipEventQuery(c->beam.ev_ready) != hipSuccess) {
-            (void)hipGetLastError();
-            PT_HIP(c, hipStreamWaitEvent(L.stream, c->beam.ev_ready, 0));
-        }
+        hipEvent_t beam_wait = nullptr;
+        if ((st = beam_cache_lookup(c, pm, &beam_lists, &beam_wait)) != PT_OK) return st;
+        if (beam_wait) PT_HIP(c, hipStreamWaitEvent(L.stream, beam_wait, 0));
     } else {
         c->beam.last_key.clear();
     }
@@ -952,6 +1045,14 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         return PT_OK;
     };
     st = submit();
+    if (c->beam.pending.want) {
+        // a moving camera's next beam lists, behind this frame's kernels on its lane
+        auto& P = c->beam.pending;
+        P.want = false;
+        // (On a side stream the build loses: at the default priority it starves behind the lanes' queues -- 8-26 of 300 frames found lists --, at
+        // the lanes' priority it is a fourth stream in their pool: 0.098 ms per frame against 0.086 without lists.  tools/experiments/README.md)
+        if (st == PT_OK) { P.dst->first_call = P.first_call; st = beam_build(c, pm, P.dst, P.centre, P.slack, std::move(P.key), L.stream); }
+    }
     // this frame's queue sizes reach h_prev_counts when the lane's next frame folds them (frame_counters_begin): no copy call
     L.prev_signature = signature;  // (the launch-grid estimates above only use them at 1 spp; pt_get_queue_sizes reports them always)
     if (L.stream != c->stream) {
@@ -1113,8 +1214,10 @@ void pt_destroy(PtContext* c)
         if (L.stream && L.stream != c->stream) (void)hipStreamDestroy(L.stream);
     }
     free_dev(c->d_sph); free_dev(c->d_mats); free_dev(c->d_nodes); free_dev(c->d_wide); free_dev(c->d_sph_sorted); free_dev(c->d_sorted_id); free_dev(c->d_lights); free_dev(c->d_alpha_class); free_dev(c->d_leaf_ids);
-    free_dev(c->beam.d_lists);
-    if (c->beam.ev_ready) (void)hipEventDestroy(c->beam.ev_ready);
+    for (auto& b : c->beam.buf) {
+        free_dev(b.d_lists);
+        if (b.ev_ready) (void)hipEventDestroy(b.ev_ready);
+    }
     if (c->beam.ev_last_use) (void)hipEventDestroy(c->beam.ev_last_use);
     if (c->beam.stream) (void)hipStreamDestroy(c->beam.stream);
     free_dev(c->d_out);
@@ -1147,6 +1250,8 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
             return fail(c, PT_ERR_INVALID_ARG, "pt_set_scene: sphere " + std::to_string(i) + " has a non-finite centre or non-positive radius");
     PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, sync_all(c));  // frames in flight still read the old scene
+    float min_radius = std::numeric_limits<float>::infinity();  // (primary-beam lists of a moving camera: their slack is bounded by it)
+    for (uint32_t i = 0; i < n && !empty; i++) min_radius = std::min(min_radius, spheres[i].r);
     // the emitters, in id order (LightPreparation::CountLights, Source/LightPreparation.ixx:52-70: objects with any emission > 0)
     std::vector<uint32_t> lights;
     for (uint32_t i = 0; i < n; i++) {
@@ -1172,6 +1277,7 @@ PtStatus pt_set_scene(PtContext* c, const PtSphere* spheres, const PtMaterial* m
         return fail(c, PT_ERR_OOM, "pt_set_scene: out of device memory (the previous scene is unchanged)");
     }
     c->empty_scene = empty;  // (after every check that can reject the call)
+    c->min_radius = min_radius;
     if (new_sph) { free_dev(c->d_sph); free_dev(c->d_mats); c->d_sph = new_sph; c->d_mats = new_mats; }
     free_dev(c->d_lights);
     c->d_lights = new_lights;

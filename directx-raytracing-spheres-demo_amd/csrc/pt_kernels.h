@@ -20,7 +20,7 @@ uint32_t traverse_lds_bytes_for(uint32_t n_nodes, uint32_t n, uint32_t depth, bo
 hipError_t launch_primary(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, const RayQueue& q, const Scratch& scratch,
                           float4* out, const FrameCounters& fc, uint32_t grid, hipStream_t stream);
 // primary beams: per-8x8-block candidate sphere lists for the primary pass (lists: pm.n_slots / 64 records of 16 dwords)
-hipError_t launch_beams(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, uint32_t* lists, hipStream_t stream);
+hipError_t launch_beams(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, float slack, uint32_t* lists, hipStream_t stream);
 hipError_t launch_traverse(const SceneView& sv, const RayQueue& q, const uint32_t* count_ptr, uint32_t grid, hipStream_t stream);
 hipError_t launch_traverse_dyn(const SceneView& sv, const RayQueue& q, const uint32_t* count_ptr, uint32_t* cursor, unsigned long long* totals, uint32_t grid,
                                hipStream_t stream);

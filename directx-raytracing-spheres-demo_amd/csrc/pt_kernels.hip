@@ -554,7 +554,7 @@ hipError_t launch_traverse_dyn(const SceneView& sv, const RayQueue& q, const uin
     return hipGetLastError();
 }
 
-hipError_t launch_beams(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, uint32_t* lists, hipStream_t stream)
+hipError_t launch_beams(const SceneView& sv, const PixelMap& pm, const FrameParams& fp, float slack, uint32_t* lists, hipStream_t stream)
 {
     const uint32_t n_blocks = pm.n_slots >> 6;
     if (n_blocks == 0) return hipSuccess;
@@ -565,7 +565,7 @@ hipError_t launch_beams(const SceneView& sv, const PixelMap& pm, const FramePara
 #define PT_BEAM(L, T)                                                                                                                            \
     do {                                                                                                                                          \
         if (lds + kStaticLdsMargin > 65536u) (void)hipFuncSetAttribute((const void*)beam_kernel<L, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((beam_kernel<L, T>), dim3(grid), dim3(256), lds, stream, sv, pm, fp, lists);                                           \
+        hipLaunchKernelGGL((beam_kernel<L, T>), dim3(grid), dim3(256), lds, stream, sv, pm, fp, slack, lists);                                           \
     } while (0)
     if (sv.lds_scene) { if (small) PT_BEAM(true, uint16_t); else PT_BEAM(true, uint32_t); }
     else { if (small) PT_BEAM(false, uint16_t); else PT_BEAM(false, uint32_t); }

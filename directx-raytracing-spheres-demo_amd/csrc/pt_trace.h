@@ -355,6 +355,8 @@ constexpr uint32_t kBeamRecord = 16;
 struct Beam {
     f3 o;
     f3 n[4];  // inward unit normals of the four side planes (zero vector = plane that culls nothing)
+    float slack;  // every plane is moved outwards by this distance: the lists then hold for every camera position within `slack` of o
+                  // (same orientation): a point x of the pyramid with apex o' has n.(x - o) = n.(x - o') + n.(o' - o) >= -|o' - o|
 };
 
 __device__ __forceinline__ f3 beam_plane(f3 a, f3 b, f3 inside)
@@ -366,7 +368,7 @@ __device__ __forceinline__ f3 beam_plane(f3 a, f3 b, f3 inside)
     return n * __builtin_amdgcn_rsqf(l2);
 }
 
-__device__ __forceinline__ Beam make_beam(const CameraParams& cam, uint32_t px, uint32_t py)
+__device__ __forceinline__ Beam make_beam(const CameraParams& cam, uint32_t px, uint32_t py, float slack)
 {
     // NDC of the block's outline: its pixel centres lie in [px, px + 8] for every jitter in [-0.5, 0.5] (the host checks the
     // jitter), widened by half a pixel each way -- the lists serve every frame of a resting view
@@ -378,6 +380,7 @@ __device__ __forceinline__ Beam make_beam(const CameraParams& cam, uint32_t px, 
     const f3 mid = (c00 + c11) + (c10 + c01);
     Beam b;
     b.o = cam.Position;
+    b.slack = slack;
     b.n[0] = beam_plane(c00, c10, mid);
     b.n[1] = beam_plane(c10, c11, mid);
     b.n[2] = beam_plane(c11, c01, mid);
@@ -390,7 +393,7 @@ __device__ __forceinline__ bool beam_meets_box(const Beam& b, f3 lo, f3 hi)
 {
     const f3 l = lo - b.o, h = hi - b.o;
     const float mag = pt_max(__builtin_fabsf(l.x), __builtin_fabsf(h.x)) + pt_max(__builtin_fabsf(l.y), __builtin_fabsf(h.y)) + pt_max(__builtin_fabsf(l.z), __builtin_fabsf(h.z));
-    const float margin = -4e-6f * mag;
+    const float margin = -4e-6f * (mag + b.slack) - b.slack;
     bool meets = true;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -409,7 +412,7 @@ __device__ __forceinline__ bool beam_meets_leaf(const Beam& b, f3 lo, f3 hi)
     const f3 c = (lo + hi) * 0.5f - b.o;
     const f3 e = (hi - lo) * 0.5f;
     const float r = pt_max(e.x, pt_max(e.y, e.z));
-    const float margin = -(r + 4e-6f * (__builtin_fabsf(c.x) + __builtin_fabsf(c.y) + __builtin_fabsf(c.z) + r));
+    const float margin = -(r + b.slack + 4e-6f * (__builtin_fabsf(c.x) + __builtin_fabsf(c.y) + __builtin_fabsf(c.z) + r + b.slack));
     bool meets = true;
 #pragma unroll
     for (int k = 0; k < 4; k++)
@@ -419,9 +422,10 @@ __device__ __forceinline__ bool beam_meets_leaf(const Beam& b, f3 lo, f3 hi)
 
 // kLds: the workgroup stages the tree into LDS first (LDS-resident scenes).  (Measured: 55 vs 58 us at 1080p -- a lane's walk is ~80 visits
 // of ~150 instructions, bound by instruction issue of lone waves rather than by where the nodes live; the build stays off the frames'
-// critical path, on a side stream, for resting views only.)
+// critical path: on a side stream for a resting view, behind a frame on its lane for a moving camera.  Sixteen lanes per block, each walking
+// one subtree four levels down, were measured: the same 56 us beside the frames -- the build's time is its share of a busy chip, not its chain.)
 template <bool kLds, typename StackT>
-__global__ __launch_bounds__(256) void beam_kernel(SceneView sv, PixelMap pm, FrameParams fp, uint32_t* __restrict__ lists)
+__global__ __launch_bounds__(256) void beam_kernel(SceneView sv, PixelMap pm, FrameParams fp, float slack, uint32_t* __restrict__ lists)
 {
     extern __shared__ float4 smem[];
     const uint32_t stride = blockDim.x;
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(256) void beam_kernel(SceneView sv, PixelMap pm, Fr
         const PixelRef pr = slot_to_pixel(pm, tile << 6);  // the block's first pixel
         uint32_t count = 0;
         if (pr.valid) {
-            const Beam b = make_beam(fp.cam, pr.px, pr.py);
+            const Beam b = make_beam(fp.cam, pr.px, pr.py, slack);
             if (sv.n == 1) {
                 rec[1] = ids[0];
                 count = 1;

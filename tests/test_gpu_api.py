@@ -414,3 +414,76 @@ def test_empty_scene(dxrs, host, oracle):
             assert np.array_equal(a.view(np.uint32)[..., :3], ref.view(np.uint32)[..., :3])
     finally:
         r.close()
+
+
+def test_primary_beam_lists_follow_a_moving_camera(dxrs, host, oracle, renderer):
+    """A camera that moves without turning (App::Update's translation, Source/App.cpp:531-553) keeps primary-beam lists: they are built around a
+    position a few frames ahead with a slack of a few frames' travel (Beam::slack: every plane moved outwards by that distance), renewed on the
+    side stream before they run out.  Every frame is bit-identical to the oracle whichever way its primaries were found, most frames of a
+    steady motion use lists, a turn or a jump falls back to traversal until the motion is steady again."""
+    import math
+    from util import count_mismatch
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    w, h, rect = 1920, 1080, (832, 476, 192, 96)
+    gs = dxrs.types.graphics_settings(w, h, frame_index=0, bounces=4, spp=1)
+    renderer.set_scene(spheres, materials, sd)
+    used = []
+
+    def frame(k, position, look_at=None):
+        gs.FrameIndex = k
+        cam = host.camera(w, h, position=position, look_at=look_at, jitter_index=k % 8)
+        renderer.set_constants(gs); renderer.set_camera(cam)
+        img, st = renderer.render(rect)
+        ref, ost = oracle.render(spheres, materials, sd, cam, gs, rect=rect, threads=8)
+        assert st.rays == ost.rays and count_mismatch(img, ref) == 0, (k, position)
+        used.append(bool(st.beams_used))
+
+    path = lambda k: (0.6 * math.sin(0.01 * k), 0.05 * math.sin(0.013 * k), -15.0 + 0.4 * math.cos(0.01 * k))  # bench.py --moving-camera
+    for k in range(20):
+        frame(k, path(k))
+    assert not used[0] and not used[1]          # nothing to go by yet; the first build starts on the second frame
+    assert sum(used[2:]) >= 14, used            # steady motion: lists nearly always
+    n0 = len(used)
+    frame(20, path(20), look_at=(0.5, 0.0, 0.0))   # a turn: another orientation
+    frame(21, path(21), look_at=(0.5, 0.0, 0.0))
+    assert not used[n0]
+    frame(22, (3.0, 1.0, -12.0))                   # a jump: no lists can be worth their slack
+    assert not used[-1]
+    for k in range(23, 31):
+        frame(k, (3.0 + 0.002 * (k - 22), 1.0, -12.0))  # steady again, slowly
+    assert sum(used[-5:]) >= 3, used
+    # a resting view still gets exact lists (no slack) on its third frame
+    for k in range(31, 34):
+        frame(k, (3.1, 1.0, -12.0))
+    assert used[-1]
+
+
+def test_moving_camera_frames_in_flight_match_per_ray_traversal(dxrs, host, renderer_no_beams):
+    """Three frames in flight over a moving camera: lists are taken when a build has finished, never waited for -- whatever the timing, the frames
+    equal those of a context without primary beams, bit for bit."""
+    import math
+    torch = pytest.importorskip("torch")
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    w, h, n = 640, 360, 60
+    gs = dxrs.types.graphics_settings(w, h, frame_index=0, bounces=3, spp=1)
+    cams = [host.camera(w, h, position=(0.3 * math.sin(0.02 * k), 0.0, -15.0 + 0.002 * k), jitter_index=k % 8) for k in range(n)]
+    out = {}
+    r3 = dxrs.Renderer(device=0, frames_in_flight=3)
+    try:
+        for name, r in (("beams", r3), ("plain", renderer_no_beams)):
+            r.set_scene(spheres, materials, sd)
+            bufs = [torch.empty((h * w, 4), dtype=torch.float32, device="cuda:0") for _ in range(n)]
+            r.totals(reset=True)
+            for k in range(n):
+                gs.FrameIndex = k
+                r.set_constants(gs); r.set_camera(cams[k])
+                r.render_device(bufs[k].data_ptr())
+            r.synchronize()
+            tot = r.totals(reset=True)
+            out[name] = ([b.cpu().numpy().view(np.uint32) for b in bufs], int(tot.rays), int(tot.beams_used))
+    finally:
+        r3.close()
+    assert out["plain"][2] == 0 and out["beams"][2] > n // 3, (out["plain"][2], out["beams"][2])
+    assert out["beams"][1] == out["plain"][1]
+    for k in range(n):
+        assert np.array_equal(out["beams"][0][k], out["plain"][0][k]), k
