@@ -422,7 +422,7 @@ def load_counters(workload):
     """profiles/counters_<workload>.json (rocprofv3 PMC passes, made by profiles/collect.sh) -- only if it was measured on the
     kernel sources this run uses; otherwise (None, reason)"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from source_hash import kernel_source_hash
+    from source_hash import kernel_knobs, kernel_source_hash
     path = os.path.join(ROOT, "profiles", f"counters_{workload}.json")
     try:
         c = json.load(open(path))
@@ -432,6 +432,8 @@ def load_counters(workload):
         return None, "committed counters are for another workload"
     if c.get("kernel_source_hash") != kernel_source_hash():
         return None, f"committed counters are stale (measured on kernel sources {c.get('kernel_source_hash')}, running {kernel_source_hash()})"
+    if c.get("knobs", {}) != kernel_knobs():
+        return None, f"committed counters were taken under other PT_* knobs ({c.get('knobs', {})}) than this run's ({kernel_knobs()})"
     return c, None
 
 

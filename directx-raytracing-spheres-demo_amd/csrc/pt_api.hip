@@ -827,6 +827,11 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         PT_HIP(c, hipStreamSynchronize(L.stream));
     }
     const bool di = c->gs.IsDIEnabled && c->n_lights > 0;
+    // Is the caller waiting for each frame (App::Tick -> Render -> WaitForGPU) or keeping several in flight?  Asked of the streams before this
+    // frame queues anything: all lanes drained = one frame at a time, and the frame is scheduled for latency (below: the fused form).
+    bool lanes_idle = true;
+    for (uint32_t i = 0; i < c->n_lanes && lanes_idle; i++)
+        if (hipStreamQuery(c->lanes[i].stream) != hipSuccess) { lanes_idle = false; (void)hipGetLastError(); }
     // Persistent workgroups: with the BVH staged into LDS per workgroup, 2 per CU (= the 4 waves/SIMD the kernel is built
     // for) amortise the 37 KB staging over ~4 batches of rays at 1080p / 1 spp (0.121 -> 0.116 ms per frame), from about
     // 1.5 M slots: below that 8 per CU is 4-10 % faster.  (Since the waves of a workgroup draw their tiles dynamically the
@@ -983,8 +988,10 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
             // 0.0162 ms, 640x384: 0.0397 -> 0.0323, 640x384 at 4 spp: 0.131 -> 0.107, a 1/8 share of a 1080p frame in tiles: 0.0566 ->
             // 0.0516; a single 1080p frame in flight: 0.190 -> 0.159).  From about half a million slots, with several frames in
             // flight, the separate looping pass wins (960x540: 0.0426 vs 0.0491 fused, 720p: 0.058 vs 0.076, C2: 0.089 vs 0.096,
-            // C3: 3.60 vs 3.69).  PT_FUSE_LOOP=0/1 overrides.
-            const bool fuse = seg && knob_or(c->knobs.fuse_loop, pm.n_slots < 400000u ? 1u : 0u) != 0;
+            // C3: 3.60 vs 3.69).  A 1-spp frame submitted to an idle context is such a lone frame whatever its size: fused, C2's one frame at a time
+            // takes 0.171 instead of 0.193 ms (and 0.088 instead of 0.078 with three in flight, which is why the streams are asked).
+            // PT_FUSE_LOOP=0/1 overrides.
+            const bool fuse = seg && knob_or(c->knobs.fuse_loop, (pm.n_slots < 400000u || (lanes_idle && spp == 1)) ? 1u : 0u) != 0;
             if (seg) { fc_seg.seg_counts = L.d_seg_counts; fc_seg.n_segs = primary_grid; fc_seg.seg_cap = seg_cap; fc_seg.fuse_loop = fuse ? 1u : 0u; }
             // spp > 1 with a separate looping pass over an untextured scene: the primary pass leaves each pixel's primary-hit record for the
             // samples the looping pass regenerates, and where it writes the pixel (Scratch::primary_cache)

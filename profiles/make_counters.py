@@ -13,7 +13,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-from source_hash import kernel_source_hash  # noqa: E402
+from source_hash import kernel_knobs, kernel_source_hash  # noqa: E402
 
 
 def kernel_class(name):
@@ -38,7 +38,7 @@ def main():
                 continue
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k][r["Counter_Name"]] += 1
-    out = {"workload": tag, "kernel_source_hash": kernel_source_hash(), "frames_per_pass": frames,
+    out = {"workload": tag, "kernel_source_hash": kernel_source_hash(), "knobs": kernel_knobs(), "frames_in_flight_of_the_counter_passes": 1, "frames_per_pass": frames,
            "source": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py ... --frames-in-flight 1 (profiles/collect*.sh); "
                      "FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md)", "kernels": {}}
     for k, c in agg.items():

@@ -51,3 +51,11 @@ def kernel_source_hash():
 
 if __name__ == "__main__":
     print(kernel_source_hash())
+
+
+def kernel_knobs():
+    """the PT_* environment knobs that change what the kernels do (read once, at pt_create): part of the counters' stamp -- counters taken
+    under one set of knobs say nothing about a run under another"""
+    import os
+    skip = {"PT_HIP_LIB", "PT_BENCH_REHEARSAL", "PT_PROFILE_STEPS", "PT_PROFILE_WARMUP", "PT_PROFILE_PMC_STEPS", "PT_ROCTX"}
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("PT_") and k not in skip}
