@@ -15,6 +15,9 @@ SHORT="--steps ${PT_PROFILE_PMC_STEPS:-20} --warmup 2 --prewarm 0 --no-cpu-basel
 python3 bench.py $LONG "$@" > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/bench_20_steps.json 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
+# Under the profiler frames run one at a time, and a 1-spp frame submitted to an idle context would take the one-launch latency form:
+# pin the throughput run's own choice (a separate looping pass from 400 k slots) for the traced and counted passes.
+if [ "${PT_PROFILE_PIN_SCHEDULE:-1}" = 1 ]; then export PT_FUSE_LOOP=${PT_FUSE_LOOP:-0} PT_PROFILE_PINNED=PT_FUSE_LOOP; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python3 $R/bench.py $LONG --no-cpu-baseline "$@" > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo "[collect] kernel stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o k -- python3 $R/bench.py $SHORT "$@" > $OUT/fetch.json 2> $OUT/fetch.err

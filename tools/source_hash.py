@@ -57,5 +57,8 @@ def kernel_knobs():
     """the PT_* environment knobs that change what the kernels do (read once, at pt_create): part of the counters' stamp -- counters taken
     under one set of knobs say nothing about a run under another"""
     import os
-    skip = {"PT_HIP_LIB", "PT_BENCH_REHEARSAL", "PT_PROFILE_STEPS", "PT_PROFILE_WARMUP", "PT_PROFILE_PMC_STEPS", "PT_ROCTX"}
+    skip = {"PT_HIP_LIB", "PT_BENCH_REHEARSAL", "PT_PROFILE_STEPS", "PT_PROFILE_WARMUP", "PT_PROFILE_PMC_STEPS", "PT_PROFILE_PINNED", "PT_ROCTX"}
+    # PT_PROFILE_PINNED (profiles/collect.sh): knobs set only to make the serialised counter passes run the schedule that the throughput run
+    # chooses by itself (a frame submitted to an idle context would otherwise take the latency form) -- not a different configuration
+    skip |= set(os.environ.get("PT_PROFILE_PINNED", "").split(","))
     return {k: v for k, v in sorted(os.environ.items()) if k.startswith("PT_") and k not in skip}
