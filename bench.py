@@ -59,8 +59,8 @@ def main():
                     help="tiled path, N > 1: torch.distributed.gather (default) or the C-ABI's pt_gather (falls back to torch if its self-check fails). "
                          "With the default the C-ABI exchange is still checked and timed AFTER the measurement, under a watchdog (result: config.tile_exchange.cabi_check)")
     ap.add_argument("--moving-camera", action="store_true",
-                    help="the camera pose changes every frame (a slow orbit, as App::Update's camera block moves it: Source/App.cpp:531-553), so nothing a resting view "
-                         "lets the renderer cache (primary-beam lists) applies")
+                    help="the camera position changes every frame (a slow orbit without a turn, as App::Update's camera block moves it: Source/App.cpp:531-553): the exact "
+                         "primary-beam lists of a resting view do not apply; the renderer keeps lists with slack instead (PT_BEAM_REACH=0 turns those off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="the CPU baseline renders every n-th row of each frame")
