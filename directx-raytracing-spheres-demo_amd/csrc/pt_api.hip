@@ -183,6 +183,8 @@ struct PtContext {
         bool building = false;         // launched, ev_ready not yet seen complete
         bool used = false;             // read by a frame since the build (a rebuild must wait for the lanes)
         uint64_t first_call = 0;       // the first render call whose frame may read them (BeamCache::calls)
+        uint64_t last_use_call = 0;    // the last render call whose frame was handed them
+        uint64_t built_call = 0;       // the render call that started (resting view) or completed (moving camera) their build
     };
     struct BeamCache {
         BeamLists buf[2];
@@ -192,7 +194,10 @@ struct PtContext {
         float last_pos[3] = { 0, 0, 0 };
         hipStream_t stream = nullptr;      // side stream (the builds of resting views)
         hipEvent_t ev_last_use = nullptr;  // scratch event of a rebuild (orders it after the lanes' frames in flight)
-        struct { bool want = false; BeamLists* dst = nullptr; float centre[3] = { 0, 0, 0 }; float slack = 0.0f; std::vector<uint32_t> key; uint64_t first_call = 0; } pending;  // a build to queue behind this frame
+        // a moving camera's next lists, built a share per frame inside the frames' primary passes (FrameParams::beam_job)
+        struct { bool active = false; BeamLists* dst = nullptr; std::vector<uint32_t> key; float centre[3] = { 0, 0, 0 }; float slack = 0.0f; uint32_t next_block = 0, n_blocks = 0; } inc;
+        float last_vel[3] = { 0, 0, 0 };   // the camera's travel between the two calls before this one (its change bounds how far to trust the extrapolation)
+        bool have_vel = false;
     } beam;
     uint64_t scene_gen = 0;  // bumped by everything that changes what a ray can hit
     float min_radius = 0.0f;  // smallest sphere of the scene set by pt_set_scene (bounds the slack of a moving camera's beam lists)
@@ -635,12 +640,12 @@ static PtStatus beam_build(PtContext* c, const PixelMap& pm, PtContext::BeamList
 
 // Primary-beam cache (PtContext::BeamCache).  *lists = lists that hold for this frame's view, else null; *wait = an event the frame must
 // wait for before it reads them (the first frames of a resting view), or null.
-PtStatus beam_cache_lookup(PtContext* c, const PixelMap& pm, const uint32_t** lists, hipEvent_t* wait)
+PtStatus beam_cache_lookup(PtContext* c, const PixelMap& pm, uint32_t max_job_blocks, const uint32_t** lists, hipEvent_t* wait, BeamJob* job)
 {
     *lists = nullptr;
     *wait = nullptr;
+    *job = BeamJob{};
     auto& B = c->beam;
-    B.pending.want = false;
     std::vector<uint32_t> key;
     key.reserve(32);
     auto put_f = [&](const float* v, int n) { for (int i = 0; i < n; i++) { uint32_t u; std::memcpy(&u, v + i, 4); key.push_back(u); } };
@@ -670,57 +675,120 @@ PtStatus beam_cache_lookup(PtContext* c, const PixelMap& pm, const uint32_t** li
         }
     // Lists in use first; else the other buffer's, if they hold (the newer build).  A build the host has not seen finish is waited for ON THE
     // DEVICE: the host runs many frames ahead of the GPU, so "finished" at call time means little -- what counts is the order of the streams.
-    if (holds(*nxt) && (!holds(*cur) || (nxt->slack == 0.0f && cur->slack > 0.0f && !nxt->building))) {  // (or: exact lists for a camera that has stopped, once they are there)
+    // (the other buffer's lists also when they are the newer ones and no frame would have to wait for them: a moving camera's next lists are
+    // centred further ahead, a camera that has stopped gets exact ones)
+    if (holds(*nxt) && (!holds(*cur) || (nxt->built_call > cur->built_call && !nxt->building))) {
         B.cur ^= 1;
         std::swap(cur, nxt);
     }
     if (holds(*cur)) {
         *lists = cur->d_lists;
         cur->used = true;
+        cur->last_use_call = call;
         if (cur->building) *wait = cur->ev_ready;
+    }
+    // The camera's velocity and how much it changed since the call before (for the extrapolation below)
+    const double v[3] = { (double)pos[0] - prev[0], (double)pos[1] - prev[1], (double)pos[2] - prev[2] };
+    double acc = 0.0;
+    if (same_orientation && B.have_vel) { const double d0 = v[0] - B.last_vel[0], d1 = v[1] - B.last_vel[1], d2 = v[2] - B.last_vel[2]; acc = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2); }
+    B.have_vel = same_orientation;
+    for (int i = 0; i < 3; i++) B.last_vel[i] = (float)v[i];
+    // A build in shares: this frame carries the next one -- unless the view it was planned for is gone (a turn, another rect or scene, a stop)
+    if (B.inc.active && (B.inc.key != key || step == 0.0 || !finite_pos)) { B.inc.active = false; }
+    if (B.inc.active) {
+        auto& I = B.inc;
+        const uint32_t n = std::min(max_job_blocks, I.n_blocks - I.next_block);
+        *job = BeamJob{ I.dst->d_lists, I.next_block, n, { I.centre[0], I.centre[1], I.centre[2] }, I.slack };
+        I.next_block += n;
+        I.dst->used = true;            // (a frame in flight WRITES the buffer: whatever builds into it next waits for the lanes, like after a reader)
+        I.dst->last_use_call = call;
+        if (I.next_block >= I.n_blocks) {
+            // complete with this frame.  No event: a frame starts only after the frames n_lanes and more calls before it have finished
+            // (render_common's marker on the caller's stream), so the frames from n_lanes calls on may read the lists.
+            I.active = false;
+            I.dst->key = key;
+            std::memcpy(I.dst->pos, I.centre, 12);
+            I.dst->slack = I.slack;
+            I.dst->first_call = call + c->n_lanes;
+            I.dst->building = false;
+            I.dst->built_call = call;
+        }
+        return PT_OK;
     }
     // Start a build?  Only for an orientation that has lasted two calls (a turning camera never pays), into the buffer frames do not use.
     if (!same_orientation || !finite_pos) return PT_OK;
-    float centre[3] = { pos[0], pos[1], pos[2] };
-    float slack = 0.0f;
+    const float centre[3] = { pos[0], pos[1], pos[2] };
+    // Where a build goes: never over the newest lists of this view (they may not be readable yet -- first_call -- but they are the future)
+    auto of_view = [&](const PtContext::BeamLists& b) { return !b.key.empty() && b.key == key; };
+    PtContext::BeamLists* dst = *lists ? nxt : cur;  // nothing usable in `cur`: build there (no swap needed later) ...
+    if (!*lists && of_view(*cur) && (!of_view(*nxt) || cur->built_call > nxt->built_call)) dst = nxt;  // ... unless `cur` holds what is about to become usable
     if (step == 0.0) {
         if (*lists && cur->slack == 0.0f) return PT_OK;  // resting, and served by exact lists (a camera that has just stopped swaps its widened ones for exact ones)
         if (holds(*nxt) && nxt->slack == 0.0f) return PT_OK;  // (already being built)
-    } else {
-        // Moving.  A build queued behind THIS frame on its lane is in stream order before the frame `a` calls later on the same lane, and
-        // the frames of the other lanes from then on wait for its event -- by then it has usually finished, a lone 55-us kernel behind a frame
-        // that ended a frame or two earlier.  So the lists are made for the frames a .. a + reach calls from now: centred on the position
-        // extrapolated to the middle of that span, with half the span's travel (+ 2 frames' for a changing speed) as slack, and renewed
-        // when the lists in use will have run out a + 1 calls from now.
-        const uint32_t reach = knob_or(c->knobs.beam_reach, 32u);
-        if (reach == 0u) return PT_OK;  // (PT_BEAM_REACH=0: lists for resting views only)
-        const double a = (double)c->n_lanes;
-        const double v[3] = { (double)pos[0] - prev[0], (double)pos[1] - prev[1], (double)pos[2] - prev[2] };
-        auto ahead = [&](double f, float out[3]) { for (int i = 0; i < 3; i++) out[i] = (float)((double)pos[i] + f * v[i]); };
-        float soon[3];
-        ahead(a + 1.0, soon);
-        auto covers = [&](const PtContext::BeamLists& b, const float* q) { return !b.key.empty() && b.key == key && b.slack > 0.0f && call + c->n_lanes + 1 >= b.first_call && dist(b.pos, q) <= (double)b.slack * (1.0 - 1e-4); };
-        if (covers(*cur, soon) || covers(*nxt, soon)) return PT_OK;
-        // The slack widens every pyramid by an absolute distance, so it must stay small against the spheres or the lists overflow: at most
-        // the smallest radius.  A faster camera gets lists for fewer frames; one that jumps (fewer than 4 frames' worth) gets none until it rests.
-        double span = (double)reach;
-        const double max_slack = (double)c->min_radius * 0.01 * (double)knob_or(c->knobs.beam_max_slack_pct, 100u);
-        if ((0.5 * span + 2.0) * step > max_slack) span = 2.0 * (std::floor(max_slack / step) - 2.0);
-        if (!(span >= 4.0)) return PT_OK;
-        ahead(a + 0.5 * span, centre);
-        slack = (float)((0.5 * span + 2.0) * step);
-        if (!(slack > 0.0f) || !std::isfinite(slack) || !std::isfinite(centre[0]) || !std::isfinite(centre[1]) || !std::isfinite(centre[2])) return PT_OK;
+        dst->first_call = call + 1;
+        dst->built_call = call;
+        return beam_build(c, pm, dst, centre, 0.0f, std::move(key), nullptr);  // a resting view's: one launch on the side stream; the next frame waits for it, once
     }
-    PtContext::BeamLists* dst = *lists ? nxt : cur;  // nothing usable in `cur`: build there (no swap needed later)
-    if (slack > 0.0f) {
-        // a moving camera's lists: queued by render_common behind this frame's kernels, on its lane
-        // (not for the frames before that: they would wait for this whole frame plus the build)
-        B.pending.want = true; B.pending.dst = dst; B.pending.slack = slack; B.pending.key = std::move(key); B.pending.first_call = call + c->n_lanes;
-        std::memcpy(B.pending.centre, centre, 12);
-        return PT_OK;
+    // Moving.  The lists are built in shares of max_job_blocks blocks inside the primary passes of the next n_build frames (a build as a launch
+    // of its own, behind a frame on its lane, cost that lane 60 us and the three lanes their even spacing for several frames: 0.083 ms per frame
+    // where the lists themselves would give 0.078), are readable n_lanes calls after the last share, and are made for the `reach` frames from
+    // then on: centred on the position extrapolated to the middle of that span, with half the span's travel, two frames' and what the
+    // velocity's last change would add up to over the extrapolation as slack.  The next build starts when the lists in use will have run out
+    // by the time it could be ready.
+    const uint32_t reach = knob_or(c->knobs.beam_reach, 32u);
+    if (reach == 0u || max_job_blocks == 0u) return PT_OK;  // (PT_BEAM_REACH=0: lists for resting views only)
+    const size_t n_blocks = pm.n_slots >> 6;
+    if (n_blocks == 0) return PT_OK;
+    const double n_build = (double)((n_blocks + max_job_blocks - 1) / max_job_blocks), a = (double)c->n_lanes;
+    auto ahead = [&](double f, float out[3]) { for (int i = 0; i < 3; i++) out[i] = (float)((double)pos[i] + f * v[i]); };
+    float then[3];
+    ahead(n_build + a + 1.0, then);
+    auto covers = [&](const PtContext::BeamLists& b, const float* q) { return !b.key.empty() && b.key == key && b.slack > 0.0f && dist(b.pos, q) <= (double)b.slack * (1.0 - 1e-4); };
+    // (one build straight after the other was measured too: 200 of 300 frames find lists instead of 281 -- all but the first build's 19 -- because
+    // a buffer must rest n_lanes calls between its last reader and its next build: 0.0815 against 0.0795 ms)
+    if (covers(*cur, then) || covers(*nxt, then)) return PT_OK;
+    // frames in flight may still read the buffer's previous lists: they were handed out no later than last_use_call, and a frame starts only
+    // after the frames n_lanes and more calls before it have finished
+    if (dst->last_use_call != 0 && call < dst->last_use_call + c->n_lanes) return PT_OK;
+    if (dst->building) return PT_OK;  // (a resting view's build on the side stream still writes it)
+    // The slack widens every pyramid by an absolute distance: at most the smallest radius (wider lists cost little -- 0.3 % of a frame at half
+    // that -- but every block overflows in the end).  A faster camera gets lists for fewer frames; one that jumps gets none until it settles.
+    double span = (double)reach;
+    const double max_slack = (double)c->min_radius * 0.01 * (double)knob_or(c->knobs.beam_max_slack_pct, 100u);
+    auto slack_for = [&](double sp) { const double t = n_build + a + 0.5 * sp; return (0.5 * sp + 2.0) * step + 0.75 * acc * t * t; };
+    while (span >= 4.0 && slack_for(span) > max_slack) span -= 2.0;
+    if (!(span >= 4.0)) return PT_OK;
+    const float slack = (float)slack_for(span);
+    float mid[3];
+    ahead(n_build - 1.0 + a + 0.5 * span, mid);
+    if (!(slack > 0.0f) || !std::isfinite(slack) || !std::isfinite(mid[0]) || !std::isfinite(mid[1]) || !std::isfinite(mid[2])) return PT_OK;
+    if (n_blocks > dst->cap_blocks) {
+        PT_HIP(c, sync_all(c));  // frames in flight may read the old lists
+        if (B.stream) PT_HIP(c, hipStreamSynchronize(B.stream));
+        free_dev(dst->d_lists);
+        dst->cap_blocks = 0;
+        PT_HIP(c, hipMalloc(&dst->d_lists, n_blocks * 16u * sizeof(uint32_t)));
+        dst->cap_blocks = n_blocks;
     }
-    dst->first_call = call + 1;
-    return beam_build(c, pm, dst, centre, slack, std::move(key), nullptr);  // a resting view's: on the side stream; the next frame waits for it, once
+    dst->key.clear();  // (nothing may take the buffer's old lists from here on)
+    dst->used = true;   // (written by frames in flight from now on)
+    dst->last_use_call = call;
+    auto& I = B.inc;
+    I.active = true; I.dst = dst; I.key = key; I.slack = slack; I.next_block = 0; I.n_blocks = (uint32_t)n_blocks;
+    std::memcpy(I.centre, mid, 12);
+    const uint32_t n = std::min(max_job_blocks, I.n_blocks);
+    *job = BeamJob{ dst->d_lists, 0u, n, { mid[0], mid[1], mid[2] }, slack };
+    I.next_block = n;
+    if (I.next_block >= I.n_blocks) {
+        I.active = false;
+        dst->key = std::move(key);
+        std::memcpy(dst->pos, mid, 12);
+        dst->slack = slack;
+        dst->first_call = call + c->n_lanes;
+        dst->building = false;
+        dst->built_call = call;
+    }
+    return PT_OK;
 }
 
 // Moving spheres (row N2).  Every lane owns a copy of what moves (spheres, Morton-ordered spheres, node boxes) and a pinned staging
@@ -860,9 +928,11 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     // build: the animated C2 frame went from 0.099 to 0.117 ms -- the build lengthens the frame's dependent chain by more than the
     // primary pass gains.  Animated scenes get none.)
     const uint32_t* beam_lists = nullptr;
+    BeamJob beam_job{};
     if (!split && !L.scene_private && c->n_nodes > 0 && knob_or(c->knobs.beams, 1u) != 0 && std::fabs(c->cam.Jitter[0]) <= 0.5f && std::fabs(c->cam.Jitter[1]) <= 0.5f) {
         hipEvent_t beam_wait = nullptr;
-        if ((st = beam_cache_lookup(c, pm, &beam_lists, &beam_wait)) != PT_OK) return st;
+        // (a share of a build rides on the first wave of up to 32 workgroups of the primary pass, 64 blocks each)
+        if ((st = beam_cache_lookup(c, pm, std::min(primary_grid, 32u) * 64u, &beam_lists, &beam_wait, &beam_job)) != PT_OK) return st;
         if (beam_wait) PT_HIP(c, hipStreamWaitEvent(L.stream, beam_wait, 0));
     } else {
         c->beam.last_key.clear();
@@ -897,6 +967,7 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     const SceneView sv = make_scene_view(c, &L);
     FrameParams fp = make_frame_params(c);
     fp.beam_lists = beam_lists;
+    fp.beam_job = beam_job;
     L.parity ^= 1u;
     const FrameCounters fc = make_counters(L, L.parity);
     uint32_t* counts = fc.counts;
@@ -1052,13 +1123,10 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
         return PT_OK;
     };
     st = submit();
-    if (c->beam.pending.want) {
-        // a moving camera's next beam lists, behind this frame's kernels on its lane
-        auto& P = c->beam.pending;
-        P.want = false;
-        // (On a side stream the build loses: at the default priority it starves behind the lanes' queues -- 8-26 of 300 frames found lists --, at
-        // the lanes' priority it is a fourth stream in their pool: 0.098 ms per frame against 0.086 without lists.  tools/experiments/README.md)
-        if (st == PT_OK) { P.dst->first_call = P.first_call; st = beam_build(c, pm, P.dst, P.centre, P.slack, std::move(P.key), L.stream); }
+    if (st != PT_OK && beam_job.n_blocks) {
+        // the share this frame was to carry is lost: the lists it belongs to must never be taken
+        c->beam.inc.active = false;
+        for (auto& b : c->beam.buf) if (b.d_lists == beam_job.lists) b.key.clear();
     }
     // this frame's queue sizes reach h_prev_counts when the lane's next frame folds them (frame_counters_begin): no copy call
     L.prev_signature = signature;  // (the launch-grid estimates above only use them at 1 spp; pt_get_queue_sizes reports them always)

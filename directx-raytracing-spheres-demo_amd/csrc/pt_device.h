@@ -145,6 +145,15 @@ __device__ __forceinline__ PixelRef slot_to_pixel(const PixelMap& m, uint32_t sl
     return r;
 }
 
+// a share of a primary-beam list build carried by a primary pass (bounce_kernel): blocks [first_block, first_block + n_blocks) of `lists`,
+// for a camera at `centre` (this frame's orientation) with Beam::slack `slack`; n_blocks = 0: none
+struct BeamJob {
+    uint32_t* lists;
+    uint32_t first_block, n_blocks;
+    float centre[3];
+    float slack;
+};
+
 struct FrameParams {
     CameraParams cam;
     uint32_t frame_index, bounces, spp, rr_enabled;
@@ -152,6 +161,7 @@ struct FrameParams {
     float inv_spp;        // 1 / (float)spp
     uint32_t di_enabled;  // IsDIEnabled and the scene has emitters: Scratch::di holds this frame's estimate
     const uint32_t* beam_lists;  // primary beams: one 16-dword record per 64 slots {count, sphere ids}; null = every primary ray traverses
+    BeamJob beam_job;
 };
 
 // Per-frame device counters, double buffered by frame parity so that the first kernel of a frame can append to this

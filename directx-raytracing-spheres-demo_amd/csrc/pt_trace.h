@@ -420,6 +420,45 @@ __device__ __forceinline__ bool beam_meets_leaf(const Beam& b, f3 lo, f3 hi)
     return meets;
 }
 
+// One lane's work for one 8x8 block: walk the tree with the block's pyramid and write the block's record.
+template <typename StackT>
+__device__ __forceinline__ void beam_walk_block(const SceneView& sv, const float4* nodes, const uint32_t* ids, StackT* stack, uint32_t stride, const PixelMap& pm,
+                                                const CameraParams& cam, float slack, uint32_t tile, uint32_t* __restrict__ lists)
+{
+    uint32_t* rec = lists + (size_t)tile * kBeamRecord;
+    const PixelRef pr = slot_to_pixel(pm, tile << 6);  // the block's first pixel
+    uint32_t count = 0;
+    if (pr.valid) {
+        const Beam b = make_beam(cam, pr.px, pr.py, slack);
+        if (sv.n == 1) {
+            rec[1] = ids[0];
+            count = 1;
+        } else {
+            int node = 0;
+            uint32_t sp = 0;
+            for (;;) {
+                if (node >= 0) {
+                    const float4 n0 = nodes[node * 4 + 0], n1 = nodes[node * 4 + 1], n2 = nodes[node * 4 + 2], n3 = nodes[node * 4 + 3];
+                    const f3 lo0 = make_f3(n0.x, n0.y, n0.z), hi0 = make_f3(n0.w, n1.x, n1.y), lo1 = make_f3(n1.z, n1.w, n2.x), hi1 = make_f3(n2.y, n2.z, n2.w);
+                    const int c0 = __builtin_bit_cast(int, n3.x), c1 = __builtin_bit_cast(int, n3.y);
+                    const bool h0 = c0 >= 0 ? beam_meets_box(b, lo0, hi0) : (beam_meets_box(b, lo0, hi0) && beam_meets_leaf(b, lo0, hi0));
+                    const bool h1 = c1 >= 0 ? beam_meets_box(b, lo1, hi1) : (beam_meets_box(b, lo1, hi1) && beam_meets_leaf(b, lo1, hi1));
+                    if (h0 && h1) { stack[sp] = stack_encode<StackT>(c1); sp += stride; node = c0; continue; }
+                    if (h0) { node = c0; continue; }
+                    if (h1) { node = c1; continue; }
+                } else {
+                    if (count < kBeamListCap) rec[1 + count] = ids[~(uint32_t)node];
+                    if (++count > kBeamListCap) break;  // overflow: the wave will traverse per ray
+                }
+                if (sp == 0) break;
+                sp -= stride;
+                node = stack_decode(stack[sp]);
+            }
+        }
+    }
+    rec[0] = count;
+}
+
 // kLds: the workgroup stages the tree into LDS first (LDS-resident scenes).  (Measured: 55 vs 58 us at 1080p -- a lane's walk is ~80 visits
 // of ~150 instructions, bound by instruction issue of lone waves rather than by where the nodes live; the build stays off the frames'
 // critical path: on a side stream for a resting view, behind a frame on its lane for a moving camera.  Sixteen lanes per block, each walking
@@ -442,40 +481,8 @@ __global__ __launch_bounds__(256) void beam_kernel(SceneView sv, PixelMap pm, Fr
         stack = reinterpret_cast<StackT*>(smem);
     }
     stack += threadIdx.x;
-    for (uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x; tile < n_blocks; tile += gridDim.x * blockDim.x) {
-        uint32_t* rec = lists + (size_t)tile * kBeamRecord;
-        const PixelRef pr = slot_to_pixel(pm, tile << 6);  // the block's first pixel
-        uint32_t count = 0;
-        if (pr.valid) {
-            const Beam b = make_beam(fp.cam, pr.px, pr.py, slack);
-            if (sv.n == 1) {
-                rec[1] = ids[0];
-                count = 1;
-            } else {
-                int node = 0;
-                uint32_t sp = 0;
-                for (;;) {
-                    if (node >= 0) {
-                        const float4 n0 = nodes[node * 4 + 0], n1 = nodes[node * 4 + 1], n2 = nodes[node * 4 + 2], n3 = nodes[node * 4 + 3];
-                        const f3 lo0 = make_f3(n0.x, n0.y, n0.z), hi0 = make_f3(n0.w, n1.x, n1.y), lo1 = make_f3(n1.z, n1.w, n2.x), hi1 = make_f3(n2.y, n2.z, n2.w);
-                        const int c0 = __builtin_bit_cast(int, n3.x), c1 = __builtin_bit_cast(int, n3.y);
-                        const bool h0 = c0 >= 0 ? beam_meets_box(b, lo0, hi0) : (beam_meets_box(b, lo0, hi0) && beam_meets_leaf(b, lo0, hi0));
-                        const bool h1 = c1 >= 0 ? beam_meets_box(b, lo1, hi1) : (beam_meets_box(b, lo1, hi1) && beam_meets_leaf(b, lo1, hi1));
-                        if (h0 && h1) { stack[sp] = stack_encode<StackT>(c1); sp += stride; node = c0; continue; }
-                        if (h0) { node = c0; continue; }
-                        if (h1) { node = c1; continue; }
-                    } else {
-                        if (count < kBeamListCap) rec[1 + count] = ids[~(uint32_t)node];
-                        if (++count > kBeamListCap) break;  // overflow: the wave will traverse per ray
-                    }
-                    if (sp == 0) break;
-                    sp -= stride;
-                    node = stack_decode(stack[sp]);
-                }
-            }
-        }
-        rec[0] = count;
-    }
+    for (uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x; tile < n_blocks; tile += gridDim.x * blockDim.x)
+        beam_walk_block<StackT>(sv, nodes, ids, stack, stride, pm, fp.cam, slack, tile, lists);
 }
 
 // Closest hit of a primary ray over its block's candidate list (wave-uniform loop; sphere records come through the scalar
@@ -956,6 +963,19 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t my_rays = 0;
+    // A share of the NEXT primary-beam lists of a moving camera (FrameParams::beam_job, pt_api.hip beam_cache_lookup): the first wave of the
+    // first workgroups walks 64 blocks' pyramids each, one lane per block, before it joins its workgroup's tiles -- a 2048-block share per
+    // frame hides in the pass (its other waves take the tiles meanwhile), where a whole build as a launch of its own stalled a lane for 60 us
+    // and put the three lanes out of step for several frames (tools/experiments/moving_trace.sh).
+    if (kPrimary && !kLoop && wave == 0) {
+        const BeamJob job = cold_arg<BeamJob>(offsetof(BounceArgHead, fp) + offsetof(FrameParams, beam_job));
+        const uint32_t j = blockIdx.x * 64u + lane;
+        if (j < job.n_blocks) {
+            CameraParams cam_b = cold_arg<CameraParams>(offsetof(BounceArgHead, fp) + offsetof(FrameParams, cam));
+            cam_b.Position = make_f3(job.centre[0], job.centre[1], job.centre[2]);
+            beam_walk_block<StackT>(sv, nodes, ids, stack, blockDim.x, cold_arg<PixelMap>(offsetof(BounceArgHead, pm)), cam_b, job.slack, job.first_block + j, job.lists);
+        }
+    }
     // Work distribution: a static grid-stride over the batches -- except for the looping pass behind a segmented hand-over,
     // where every WAVE pulls its next 64 entries from a work cursor (one atomic per 64 paths; no barrier inside this loop in
     // the looping form): a segment lists one workgroup's tiles top to bottom of the image, and a static stride over such a
