@@ -170,9 +170,10 @@ struct PtContext {
     // Primary beams (DESIGN.md "Primary beams"): per-8x8-block candidate sphere lists for the primary pass.  They depend on the
     // camera's orientation, the frame geometry and the scene, and on the camera's POSITION up to the slack they were built with
     // (Beam::slack) -- not on the frame index or the jitter (the beams are a pixel wider than the blocks).  A view that RESTS gets
-    // lists with no slack on its second frame; a camera that moves without turning gets lists centred a few frames ahead of it
-    // with a slack of a few frames' travel, rebuilt on a side stream while the frames use the previous ones -- a frame never waits
-    // for a build of the moving kind: it takes the newest lists that are ready and hold for its pose, or traverses per ray.
+    // lists with no slack on its second frame (one launch on a side stream); a camera that moves without turning gets lists
+    // centred some frames ahead of it with a slack of a few frames' travel, built in shares inside the frames' own primary passes
+    // while the frames use the previous ones -- a frame never waits for a build of the moving kind: it takes the newest lists that
+    // are readable and hold for its pose, or traverses per ray.
     struct BeamLists {
         uint32_t* d_lists = nullptr;   // n_blocks records of 16 dwords
         size_t cap_blocks = 0;
