@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--moving-camera", action="store_true",
                     help="the camera position changes every frame (a slow orbit without a turn, as App::Update's camera block moves it: Source/App.cpp:531-553): the exact "
                          "primary-beam lists of a resting view do not apply; the renderer keeps lists with slack instead (PT_BEAM_REACH=0 turns those off)")
+    ap.add_argument("--turning-camera", action="store_true",
+                    help="the camera turns every frame (a slow yaw with a little pitch, 1.3e-4 rad per frame -- 95 degrees per second at this frame rate -- as App::Update's "
+                         "mouse look turns it); with --moving-camera it travels as well")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=1, help="the CPU baseline renders every n-th row of each frame")
@@ -137,11 +140,13 @@ def main():
     gs = graphics_settings(w, h, frame_index=0, bounces=args.bounces, spp=args.spp, di=args.di)
     r.set_constants(gs)
     cams = [host.camera(w, h, jitter_index=k, jitter_count=8) for k in range(8)]
-    if args.moving_camera:
+    if args.moving_camera or args.turning_camera:
         import math
         n_cam = 3 * args.steps + args.warmup + 64
-        cams = [host.camera(w, h, position=(0.6 * math.sin(0.01 * k), 0.05 * math.sin(0.013 * k), -15.0 + 0.4 * math.cos(0.01 * k)), jitter_index=k % 8, jitter_count=8)
-                for k in range(n_cam)]
+        where = (lambda k: (0.6 * math.sin(0.01 * k), 0.05 * math.sin(0.013 * k), -15.0 + 0.4 * math.cos(0.01 * k))) if args.moving_camera else (lambda k: (0.0, 0.0, -15.0))
+        # (look_at = None: the demo camera's fixed orientation; turning: the point looked at wanders, 15 units ahead)
+        aim = (lambda k: (2.0 * math.sin(0.001 * k), 0.5 * math.sin(0.0013 * k), 0.0)) if args.turning_camera else (lambda k: None)
+        cams = [host.camera(w, h, position=where(k), look_at=aim(k), jitter_index=k % 8, jitter_count=8) for k in range(n_cam)]
 
     def set_frame(k, rr=None):
         rr = rr or r
@@ -310,7 +315,7 @@ def main():
                 "prewarm_frames": prewarm,
                 "one_frame_at_a_time": serial,
                 "animated": bool(args.animate),
-                "moving_camera": bool(args.moving_camera),
+                "moving_camera": bool(args.moving_camera), "turning_camera": bool(args.turning_camera),
                 # the primary pass of a RESTING view takes its candidates from cached per-block sphere lists (DESIGN.md "Primary beams"); a moving
                 # camera or an animated scene traverses per ray -- run with --moving-camera / --animate for those figures
                 "primary_beams": {"frames_using_cached_lists": int(tot.beams_used), "of": args.steps},

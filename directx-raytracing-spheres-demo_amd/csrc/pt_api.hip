@@ -42,7 +42,7 @@ struct EventPair {
 struct Knobs {
     int split = -1, traverse_blocks_per_cu = -1, fused_threads = -1, no_adaptive_grid = -1, shade_blocks_per_cu = -1, tail_threshold = -1,
         tail_blocks_per_cu = -1, loop_threads = -1, inline2_min_slots = -1, tail_after = -1, seg = -1, loop_use_tail = -1, fuse_loop = -1,
-        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1, lane_priority = -1, fused_refit = -1, beam_reach = -1, beam_max_slack_pct = -1;
+        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1, lane_priority = -1, fused_refit = -1, beam_reach = -1, beam_max_slack_pct = -1, beam_max_margin = -1;
 };
 
 // Per-frame-in-flight state (see PtContext::lanes).
@@ -180,6 +180,8 @@ struct PtContext {
         std::vector<uint32_t> key;     // orientation, frame geometry, scene generation of the lists in d_lists; empty = none
         float pos[3] = { 0, 0, 0 };    // the camera position they were built around ...
         float slack = 0.0f;            // ... and how far from it they hold
+        float basis[9] = {};           // the orientation (Right, Up, Forward) they were built for ...
+        float margin_px = 0.0f;        // ... and by how many pixels a ray's crossing of the image may differ from that orientation's
         hipEvent_t ev_ready = nullptr;   // the build has finished
         bool building = false;         // launched, ev_ready not yet seen complete
         bool used = false;             // read by a frame since the build (a rebuild must wait for the lanes)
@@ -196,8 +198,10 @@ struct PtContext {
         hipStream_t stream = nullptr;      // side stream (the builds of resting views)
         hipEvent_t ev_last_use = nullptr;  // scratch event of a rebuild (orders it after the lanes' frames in flight)
         // a moving camera's next lists, built a share per frame inside the frames' primary passes (FrameParams::beam_job)
-        struct { bool active = false; BeamLists* dst = nullptr; std::vector<uint32_t> key; float centre[3] = { 0, 0, 0 }; float slack = 0.0f; uint32_t next_block = 0, n_blocks = 0; } inc;
+        struct { bool active = false; BeamLists* dst = nullptr; std::vector<uint32_t> key; float centre[3] = { 0, 0, 0 }; float slack = 0.0f; float basis[9] = {}; float margin_px = 0.0f; uint32_t next_block = 0, n_blocks = 0; } inc;
         float last_vel[3] = { 0, 0, 0 };   // the camera's travel between the two calls before this one (its change bounds how far to trust the extrapolation)
+        double last_turn[3] = { 0, 0, 0 }; // ... and its turn (rotation vector)
+        float last_basis[9] = {};          // orientation of the previous render call
         bool have_vel = false;
     } beam;
     uint64_t scene_gen = 0;  // bumped by everything that changes what a ray can hit
@@ -528,7 +532,7 @@ Knobs read_knobs()
     k.no_adaptive_grid = std::getenv("PT_NO_ADAPTIVE_GRID") ? 1 : -1; k.shade_blocks_per_cu = env_knob("PT_SHADE_BLOCKS_PER_CU");
     k.tail_threshold = env_knob("PT_TAIL_THRESHOLD"); k.tail_blocks_per_cu = env_knob("PT_TAIL_BLOCKS_PER_CU"); k.loop_threads = env_knob("PT_LOOP_THREADS");
     k.inline2_min_slots = env_knob("PT_INLINE2_MIN_SLOTS"); k.tail_after = env_knob("PT_TAIL_AFTER"); k.seg = env_knob("PT_SEG");
-    k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.beam_reach = env_knob("PT_BEAM_REACH"); k.beam_max_slack_pct = env_knob("PT_BEAM_MAX_SLACK_PCT"); k.lane_priority = env_knob("PT_LANE_PRIORITY"); k.fused_refit = env_knob("PT_FUSED_REFIT"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
+    k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.beam_reach = env_knob("PT_BEAM_REACH"); k.beam_max_slack_pct = env_knob("PT_BEAM_MAX_SLACK_PCT"); k.beam_max_margin = env_knob("PT_BEAM_MAX_MARGIN"); k.lane_priority = env_knob("PT_LANE_PRIORITY"); k.fused_refit = env_knob("PT_FUSED_REFIT"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
     k.dyn_blocks_per_cu = env_knob("PT_DYN_BLOCKS_PER_CU"); k.debug_counts = std::getenv("PT_DEBUG_COUNTS") ? 1 : -1; k.sah = env_knob("PT_SAH");
     k.sah_max_spheres = env_knob("PT_SAH_MAX_SPHERES"); k.beams = env_knob("PT_BEAMS"); k.wide = env_knob("PT_WIDE"); k.descent = env_knob("PT_DESCENT"); k.roctx = env_knob("PT_ROCTX");
     return k;
@@ -647,26 +651,71 @@ PtStatus beam_cache_lookup(PtContext* c, const PixelMap& pm, uint32_t max_job_bl
     *wait = nullptr;
     *job = BeamJob{};
     auto& B = c->beam;
+    // What the lists of a view have in common whatever the camera's pose: the frame geometry, the scene (the key) and the lens -- the lengths of
+    // the camera's axes, which a turning camera reproduces only to rounding: compared in pixels (lens_px), like the turn itself.
+    auto len3 = [](const float* v) { return std::sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]); };
+    const double len_r = len3(c->cam.RightDirection), len_u = len3(c->cam.UpDirection), len_f = len3(c->cam.ForwardDirection);
     std::vector<uint32_t> key;
-    key.reserve(32);
-    auto put_f = [&](const float* v, int n) { for (int i = 0; i < n; i++) { uint32_t u; std::memcpy(&u, v + i, 4); key.push_back(u); } };
-    put_f(c->cam.RightDirection, 3); put_f(c->cam.UpDirection, 3); put_f(c->cam.ForwardDirection, 3);
+    key.reserve(24);
     for (uint32_t v : { pm.mode, pm.img_w, pm.img_h, pm.rx, pm.ry, pm.rw, pm.rh, pm.ts, pm.first, pm.run, pm.stride, pm.n_slots,
                         (uint32_t)c->scene_gen, (uint32_t)(c->scene_gen >> 32) }) key.push_back(v);
     const float* pos = c->cam.Position;
+    float basis[9];  // this frame's orientation: Right, Up, Forward as the kernels use them
+    std::memcpy(basis, c->cam.RightDirection, 12); std::memcpy(basis + 3, c->cam.UpDirection, 12); std::memcpy(basis + 6, c->cam.ForwardDirection, 12);
+    bool finite_pose = std::isfinite(pos[0]) && std::isfinite(pos[1]) && std::isfinite(pos[2]) && len_r > 0.0 && len_u > 0.0 && len_f > 0.0;
+    for (float x : basis) finite_pose = finite_pose && std::isfinite(x);
     auto dist = [](const float* a, const float* b) {
         const double dx = (double)a[0] - b[0], dy = (double)a[1] - b[1], dz = (double)a[2] - b[2];
         return std::sqrt(dx * dx + dy * dy + dz * dz);
     };
-    // (the kernel's plane tests carry their own rounding margin; the host's distance is exact to double rounding, hence the 1e-4)
+    // The rotation that takes orientation p to orientation q (both with this lens) as a rotation vector (axis * angle): R = Q * P^T over the
+    // normalised axes; angle from the trace, axis from the antisymmetric part.
+    auto rotation_between = [&](const float* p, const float* q, double w[3]) {
+        double R[3][3] = {};
+        for (int k = 0; k < 3; k++) {
+            const double lp = len3(p + 3 * k), lq = len3(q + 3 * k), inv = lp > 0.0 && lq > 0.0 ? 1.0 / (lp * lq) : 0.0;
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) R[i][j] += (double)q[3 * k + i] * (double)p[3 * k + j] * inv;
+        }
+        const double ax[3] = { R[2][1] - R[1][2], R[0][2] - R[2][0], R[1][0] - R[0][1] };  // 2 sin(angle) * axis
+        const double s2 = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]), c2 = R[0][0] + R[1][1] + R[2][2] - 1.0;  // 2 sin, 2 cos
+        const double angle = std::atan2(s2, c2);
+        for (int i = 0; i < 3; i++) w[i] = s2 > 0.0 ? ax[i] / s2 * angle : 0.0;
+        return angle;  // in [0, pi]; a half turn has no axis here, and nothing below builds lists for one
+    };
+    // How far, in pixels, a ray's crossing of the image can move when the camera turns by `angle` (any axis): a direction moves by at most that
+    // angle, and at an angle a off the view axis a change of direction moves the crossing by at most f / cos^2(a) pixels per radian (f = the focal
+    // length in pixels) -- taken at the image corner, plus the turn itself.
+    const double fx_px = 0.5 * (double)pm.img_w * len_f / len_r, fy_px = 0.5 * (double)pm.img_h * len_f / len_u;  // (equal for square pixels)
+    const double f_px = std::max(fx_px, fy_px);
+    const double corner = std::atan(std::sqrt(len_r * len_r + len_u * len_u) / len_f);  // the image corner's angle off the view axis
+    auto turn_px = [&](double angle) { const double a = std::min(corner + angle, 1.55), cs = std::cos(a); return angle * f_px / (cs * cs) * 1.01; };
+    // ... and when its axes' lengths differ (by rounding: relative differences times the image's half diagonal, with the tangent at the corner)
+    const double half_diag_px = 0.5 * std::sqrt((double)pm.img_w * pm.img_w + (double)pm.img_h * pm.img_h);
+    auto lens_px = [&](const float* p, const float* q) {
+        double worst = 0.0;
+        for (int k = 0; k < 3; k++) { const double lp = len3(p + 3 * k), lq = len3(q + 3 * k); worst = std::max(worst, lp > 0.0 && lq > 0.0 ? std::fabs(lq / lp - 1.0) : 1e30); }
+        const double cs = std::cos(std::min(corner, 1.55));
+        return 2.0 * worst * half_diag_px / (cs * cs) * 1.01;
+    };
     const uint64_t call = ++B.calls;
-    auto holds = [&](const PtContext::BeamLists& b) { return !b.key.empty() && b.key == key && call >= b.first_call && (b.slack == 0.0f ? std::memcmp(b.pos, pos, 12) == 0 : dist(b.pos, pos) <= (double)b.slack * (1.0 - 1e-4)); };
-    const bool same_orientation = key == B.last_key;
-    const double step = same_orientation ? dist(pos, B.last_pos) : 0.0;  // the camera's travel since the previous call
-    const bool finite_pos = std::isfinite(pos[0]) && std::isfinite(pos[1]) && std::isfinite(pos[2]);
+    auto within = [&](const PtContext::BeamLists& b, const float* q_pos, const float* q_basis) {
+        if (b.slack == 0.0f ? std::memcmp(b.pos, q_pos, 12) != 0 : dist(b.pos, q_pos) > (double)b.slack * (1.0 - 1e-4)) return false;
+        if (std::memcmp(b.basis, q_basis, 36) == 0) return true;
+        if (b.margin_px == 0.0f) return false;
+        double w[3];
+        return turn_px(rotation_between(b.basis, q_basis, w)) + lens_px(b.basis, q_basis) <= (double)b.margin_px * (1.0 - 1e-3);
+    };
+    auto holds = [&](const PtContext::BeamLists& b) { return !b.key.empty() && b.key == key && call >= b.first_call && within(b, pos, basis); };
+    const bool same_view = finite_pose && key == B.last_key && lens_px(B.last_basis, basis) <= 0.02;  // (the pose may differ)
+    const double step = same_view ? dist(pos, B.last_pos) : 0.0;  // the camera's travel since the previous call ...
+    double turn[3] = { 0.0, 0.0, 0.0 };
+    const double turned = same_view ? rotation_between(B.last_basis, basis, turn) : 0.0;  // ... and its turn
+    const bool rested = same_view && std::memcmp(B.last_pos, pos, 12) == 0 && std::memcmp(B.last_basis, basis, 36) == 0;
     const float prev[3] = { B.last_pos[0], B.last_pos[1], B.last_pos[2] };
     B.last_key = key;
     std::memcpy(B.last_pos, pos, 12);
+    std::memcpy(B.last_basis, basis, 36);
     PtContext::BeamLists* cur = &B.buf[B.cur];
     PtContext::BeamLists* nxt = &B.buf[B.cur ^ 1];
     for (auto& b : B.buf)
@@ -688,81 +737,116 @@ PtStatus beam_cache_lookup(PtContext* c, const PixelMap& pm, uint32_t max_job_bl
         cur->last_use_call = call;
         if (cur->building) *wait = cur->ev_ready;
     }
-    // The camera's velocity and how much it changed since the call before (for the extrapolation below)
+    // The camera's velocities and how much they changed since the call before (for the extrapolation below)
     const double v[3] = { (double)pos[0] - prev[0], (double)pos[1] - prev[1], (double)pos[2] - prev[2] };
-    double acc = 0.0;
-    if (same_orientation && B.have_vel) { const double d0 = v[0] - B.last_vel[0], d1 = v[1] - B.last_vel[1], d2 = v[2] - B.last_vel[2]; acc = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2); }
-    B.have_vel = same_orientation;
-    for (int i = 0; i < 3; i++) B.last_vel[i] = (float)v[i];
-    // A build in shares: this frame carries the next one -- unless the view it was planned for is gone (a turn, another rect or scene, a stop)
-    if (B.inc.active && (B.inc.key != key || step == 0.0 || !finite_pos)) { B.inc.active = false; }
+    double acc = 0.0, turn_acc = 0.0;
+    if (same_view && B.have_vel) {
+        const double d0 = v[0] - B.last_vel[0], d1 = v[1] - B.last_vel[1], d2 = v[2] - B.last_vel[2];
+        acc = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        const double t0 = turn[0] - B.last_turn[0], t1 = turn[1] - B.last_turn[1], t2 = turn[2] - B.last_turn[2];
+        turn_acc = std::sqrt(t0 * t0 + t1 * t1 + t2 * t2);
+    }
+    B.have_vel = same_view;
+    for (int i = 0; i < 3; i++) { B.last_vel[i] = (float)v[i]; B.last_turn[i] = turn[i]; }
+    // A build in shares: this frame carries the next one -- unless the view it was planned for is gone (another lens, rect or scene, a stop)
+    if (B.inc.active && (B.inc.key != key || rested || !finite_pose)) { B.inc.active = false; }
+    auto make_job = [&](uint32_t first, uint32_t n) {
+        const auto& I = B.inc;
+        BeamJob j{};
+        j.lists = I.dst->d_lists; j.first_block = first; j.n_blocks = n; j.slack = I.slack; j.margin_px = I.margin_px;
+        std::memcpy(j.centre, I.centre, 12);
+        std::memcpy(j.right, I.basis, 12); std::memcpy(j.up, I.basis + 3, 12); std::memcpy(j.forward, I.basis + 6, 12);
+        return j;
+    };
+    auto finish = [&](PtContext::BeamLists* d) {
+        // complete with this frame.  No event: a frame starts only after the frames n_lanes and more calls before it have finished
+        // (render_common's marker on the caller's stream), so the frames from n_lanes calls on may read the lists.
+        const auto& I = B.inc;
+        d->key = key;
+        std::memcpy(d->pos, I.centre, 12);
+        std::memcpy(d->basis, I.basis, 36);
+        d->slack = I.slack;
+        d->margin_px = I.margin_px;
+        d->first_call = call + c->n_lanes;
+        d->building = false;
+        d->built_call = call;
+    };
     if (B.inc.active) {
         auto& I = B.inc;
         const uint32_t n = std::min(max_job_blocks, I.n_blocks - I.next_block);
-        *job = BeamJob{ I.dst->d_lists, I.next_block, n, { I.centre[0], I.centre[1], I.centre[2] }, I.slack };
+        *job = make_job(I.next_block, n);
         I.next_block += n;
         I.dst->used = true;            // (a frame in flight WRITES the buffer: whatever builds into it next waits for the lanes, like after a reader)
         I.dst->last_use_call = call;
-        if (I.next_block >= I.n_blocks) {
-            // complete with this frame.  No event: a frame starts only after the frames n_lanes and more calls before it have finished
-            // (render_common's marker on the caller's stream), so the frames from n_lanes calls on may read the lists.
-            I.active = false;
-            I.dst->key = key;
-            std::memcpy(I.dst->pos, I.centre, 12);
-            I.dst->slack = I.slack;
-            I.dst->first_call = call + c->n_lanes;
-            I.dst->building = false;
-            I.dst->built_call = call;
-        }
+        if (I.next_block >= I.n_blocks) { I.active = false; finish(I.dst); }
         return PT_OK;
     }
-    // Start a build?  Only for an orientation that has lasted two calls (a turning camera never pays), into the buffer frames do not use.
-    if (!same_orientation || !finite_pos) return PT_OK;
-    const float centre[3] = { pos[0], pos[1], pos[2] };
+    // Start a build?  Only for a view (lens, geometry, scene) that has lasted two calls, into the buffer frames do not use.
+    if (!same_view) return PT_OK;
     // Where a build goes: never over the newest lists of this view (they may not be readable yet -- first_call -- but they are the future)
     auto of_view = [&](const PtContext::BeamLists& b) { return !b.key.empty() && b.key == key; };
     PtContext::BeamLists* dst = *lists ? nxt : cur;  // nothing usable in `cur`: build there (no swap needed later) ...
     if (!*lists && of_view(*cur) && (!of_view(*nxt) || cur->built_call > nxt->built_call)) dst = nxt;  // ... unless `cur` holds what is about to become usable
-    if (step == 0.0) {
-        if (*lists && cur->slack == 0.0f) return PT_OK;  // resting, and served by exact lists (a camera that has just stopped swaps its widened ones for exact ones)
-        if (holds(*nxt) && nxt->slack == 0.0f) return PT_OK;  // (already being built)
+    if (rested) {
+        if (*lists && cur->slack == 0.0f && cur->margin_px == 0.0f) return PT_OK;  // resting, and served by exact lists (a camera that has just stopped swaps its widened ones for exact ones)
+        if (holds(*nxt) && nxt->slack == 0.0f && nxt->margin_px == 0.0f) return PT_OK;  // (already being built)
         dst->first_call = call + 1;
         dst->built_call = call;
-        return beam_build(c, pm, dst, centre, 0.0f, std::move(key), nullptr);  // a resting view's: one launch on the side stream; the next frame waits for it, once
+        std::memcpy(dst->basis, basis, 36);
+        dst->margin_px = 0.0f;
+        return beam_build(c, pm, dst, pos, 0.0f, std::move(key), nullptr);  // a resting view's: one launch on the side stream; the next frame waits for it, once
     }
     // Moving.  The lists are built in shares of max_job_blocks blocks inside the primary passes of the next n_build frames (a build as a launch
     // of its own, behind a frame on its lane, cost that lane 60 us and the three lanes their even spacing for several frames: 0.083 ms per frame
     // where the lists themselves would give 0.078), are readable n_lanes calls after the last share, and are made for the `reach` frames from
-    // then on: centred on the position extrapolated to the middle of that span, with half the span's travel, two frames' and what the
-    // velocity's last change would add up to over the extrapolation as slack.  The next build starts when the lists in use will have run out
-    // by the time it could be ready.
+    // then on: centred on the position -- and turned to the orientation -- extrapolated to the middle of that span, with half the span's travel,
+    // two frames' and what the velocity's last change would add up to over the extrapolation as slack, and the same of the turn, in pixels, as
+    // margin.  The next build starts when the lists in use will have run out by the time it could be ready.
     const uint32_t reach = knob_or(c->knobs.beam_reach, 32u);
     if (reach == 0u || max_job_blocks == 0u) return PT_OK;  // (PT_BEAM_REACH=0: lists for resting views only)
     const size_t n_blocks = pm.n_slots >> 6;
     if (n_blocks == 0) return PT_OK;
     const double n_build = (double)((n_blocks + max_job_blocks - 1) / max_job_blocks), a = (double)c->n_lanes;
-    auto ahead = [&](double f, float out[3]) { for (int i = 0; i < 3; i++) out[i] = (float)((double)pos[i] + f * v[i]); };
-    float then[3];
-    ahead(n_build + a + 1.0, then);
-    auto covers = [&](const PtContext::BeamLists& b, const float* q) { return !b.key.empty() && b.key == key && b.slack > 0.0f && dist(b.pos, q) <= (double)b.slack * (1.0 - 1e-4); };
+    auto ahead = [&](double f, float out_pos[3], float out_basis[9]) {
+        for (int i = 0; i < 3; i++) out_pos[i] = (float)((double)pos[i] + f * v[i]);
+        // this frame's axes turned by f times the last turn (Rodrigues), their lengths kept
+        const double ang = f * turned;
+        std::memcpy(out_basis, basis, 36);
+        if (ang > 0.0 && turned > 0.0) {
+            const double k[3] = { turn[0] / turned, turn[1] / turned, turn[2] / turned }, cs = std::cos(ang), sn = std::sin(ang);
+            for (int x = 0; x < 3; x++) {
+                const double p[3] = { basis[3 * x], basis[3 * x + 1], basis[3 * x + 2] };
+                const double kxp[3] = { k[1] * p[2] - k[2] * p[1], k[2] * p[0] - k[0] * p[2], k[0] * p[1] - k[1] * p[0] }, kp = k[0] * p[0] + k[1] * p[1] + k[2] * p[2];
+                for (int i = 0; i < 3; i++) out_basis[3 * x + i] = (float)(p[i] * cs + kxp[i] * sn + k[i] * kp * (1.0 - cs));
+            }
+        }
+    };
+    float then_pos[3], then_basis[9];
+    ahead(n_build + a + 1.0, then_pos, then_basis);
+    auto covers = [&](const PtContext::BeamLists& b) { return !b.key.empty() && b.key == key && (b.slack > 0.0f || b.margin_px > 0.0f) && within(b, then_pos, then_basis); };
     // (one build straight after the other was measured too: 200 of 300 frames find lists instead of 281 -- all but the first build's 19 -- because
     // a buffer must rest n_lanes calls between its last reader and its next build: 0.0815 against 0.0795 ms)
-    if (covers(*cur, then) || covers(*nxt, then)) return PT_OK;
+    if (covers(*cur) || covers(*nxt)) return PT_OK;
     // frames in flight may still read the buffer's previous lists: they were handed out no later than last_use_call, and a frame starts only
     // after the frames n_lanes and more calls before it have finished
     if (dst->last_use_call != 0 && call < dst->last_use_call + c->n_lanes) return PT_OK;
     if (dst->building) return PT_OK;  // (a resting view's build on the side stream still writes it)
     // The slack widens every pyramid by an absolute distance: at most the smallest radius (wider lists cost little -- 0.3 % of a frame at half
-    // that -- but every block overflows in the end).  A faster camera gets lists for fewer frames; one that jumps gets none until it settles.
+    // that -- but every block overflows in the end); the margin by pixels: at most PT_BEAM_MAX_MARGIN (8).  A faster camera gets lists for
+    // fewer frames; one that jumps or spins gets none until it settles.
     double span = (double)reach;
-    const double max_slack = (double)c->min_radius * 0.01 * (double)knob_or(c->knobs.beam_max_slack_pct, 100u);
+    const double max_slack = (double)c->min_radius * 0.01 * (double)knob_or(c->knobs.beam_max_slack_pct, 100u), max_margin = (double)knob_or(c->knobs.beam_max_margin, 8u);
     auto slack_for = [&](double sp) { const double t = n_build + a + 0.5 * sp; return (0.5 * sp + 2.0) * step + 0.75 * acc * t * t; };
-    while (span >= 4.0 && slack_for(span) > max_slack) span -= 2.0;
+    auto margin_for = [&](double sp) { const double t = n_build + a + 0.5 * sp; return turned > 0.0 || turn_acc > 0.0 ? turn_px((0.5 * sp + 2.0) * turned + 0.75 * turn_acc * t * t) + 0.05 : 0.0; };
+    while (span >= 4.0 && (slack_for(span) > max_slack || margin_for(span) > max_margin)) span -= 2.0;
     if (!(span >= 4.0)) return PT_OK;
-    const float slack = (float)slack_for(span);
-    float mid[3];
-    ahead(n_build - 1.0 + a + 0.5 * span, mid);
-    if (!(slack > 0.0f) || !std::isfinite(slack) || !std::isfinite(mid[0]) || !std::isfinite(mid[1]) || !std::isfinite(mid[2])) return PT_OK;
+    const float slack = (float)slack_for(span), margin_px = (float)margin_for(span);
+    float mid[3], mid_basis[9];
+    ahead(n_build - 1.0 + a + 0.5 * span, mid, mid_basis);
+    bool ok = (slack > 0.0f || margin_px > 0.0f) && std::isfinite(slack) && std::isfinite(margin_px);
+    for (float x : mid) ok = ok && std::isfinite(x);
+    for (float x : mid_basis) ok = ok && std::isfinite(x);
+    if (!ok) return PT_OK;
     if (n_blocks > dst->cap_blocks) {
         PT_HIP(c, sync_all(c));  // frames in flight may read the old lists
         if (B.stream) PT_HIP(c, hipStreamSynchronize(B.stream));
@@ -775,20 +859,13 @@ PtStatus beam_cache_lookup(PtContext* c, const PixelMap& pm, uint32_t max_job_bl
     dst->used = true;   // (written by frames in flight from now on)
     dst->last_use_call = call;
     auto& I = B.inc;
-    I.active = true; I.dst = dst; I.key = key; I.slack = slack; I.next_block = 0; I.n_blocks = (uint32_t)n_blocks;
+    I.active = true; I.dst = dst; I.key = key; I.slack = slack; I.margin_px = margin_px; I.next_block = 0; I.n_blocks = (uint32_t)n_blocks;
     std::memcpy(I.centre, mid, 12);
+    std::memcpy(I.basis, mid_basis, 36);
     const uint32_t n = std::min(max_job_blocks, I.n_blocks);
-    *job = BeamJob{ dst->d_lists, 0u, n, { mid[0], mid[1], mid[2] }, slack };
+    *job = make_job(0u, n);
     I.next_block = n;
-    if (I.next_block >= I.n_blocks) {
-        I.active = false;
-        dst->key = std::move(key);
-        std::memcpy(dst->pos, mid, 12);
-        dst->slack = slack;
-        dst->first_call = call + c->n_lanes;
-        dst->building = false;
-        dst->built_call = call;
-    }
+    if (I.next_block >= I.n_blocks) { I.active = false; finish(dst); }
     return PT_OK;
 }
 

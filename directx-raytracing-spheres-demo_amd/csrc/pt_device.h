@@ -152,6 +152,8 @@ struct BeamJob {
     uint32_t first_block, n_blocks;
     float centre[3];
     float slack;
+    float right[3], up[3], forward[3];  // the orientation the lists are made for (CameraParams::Right / Up / Forward)
+    float margin_px;                     // make_beam: pixels added on every side of a block's outline
 };
 
 struct FrameParams {

@@ -368,12 +368,14 @@ __device__ __forceinline__ f3 beam_plane(f3 a, f3 b, f3 inside)
     return n * __builtin_amdgcn_rsqf(l2);
 }
 
-__device__ __forceinline__ Beam make_beam(const CameraParams& cam, uint32_t px, uint32_t py, float slack)
+__device__ __forceinline__ Beam make_beam(const CameraParams& cam, uint32_t px, uint32_t py, float slack, float margin_px = 0.0f)
 {
     // NDC of the block's outline: its pixel centres lie in [px, px + 8] for every jitter in [-0.5, 0.5] (the host checks the
     // jitter), widened by half a pixel each way -- the lists serve every frame of a resting view
-    const float xa = ((float)px - 0.5f) * cam.InvW, xb = ((float)px + 8.5f) * cam.InvW;
-    const float ya = ((float)py - 0.5f) * cam.InvH, yb = ((float)py + 8.5f) * cam.InvH;
+    // (margin_px more on every side: the lists then hold for every orientation whose rays leave the image within that many pixels of where
+    // this one's do -- a camera that turns; pt_api.hip beam_cache_lookup bounds the displacement)
+    const float xa = ((float)px - 0.5f - margin_px) * cam.InvW, xb = ((float)px + 8.5f + margin_px) * cam.InvW;
+    const float ya = ((float)py - 0.5f - margin_px) * cam.InvH, yb = ((float)py + 8.5f + margin_px) * cam.InvH;
     const float nxa = pt_fma(xa, 2.0f, -1.0f), nxb = pt_fma(xb, 2.0f, -1.0f), nya = pt_fma(ya, -2.0f, 1.0f), nyb = pt_fma(yb, -2.0f, 1.0f);
     const f3 c00 = mad(nya, cam.Up, cam.Right * nxa) + cam.Forward, c10 = mad(nya, cam.Up, cam.Right * nxb) + cam.Forward;
     const f3 c11 = mad(nyb, cam.Up, cam.Right * nxb) + cam.Forward, c01 = mad(nyb, cam.Up, cam.Right * nxa) + cam.Forward;
@@ -423,13 +425,13 @@ __device__ __forceinline__ bool beam_meets_leaf(const Beam& b, f3 lo, f3 hi)
 // One lane's work for one 8x8 block: walk the tree with the block's pyramid and write the block's record.
 template <typename StackT>
 __device__ __forceinline__ void beam_walk_block(const SceneView& sv, const float4* nodes, const uint32_t* ids, StackT* stack, uint32_t stride, const PixelMap& pm,
-                                                const CameraParams& cam, float slack, uint32_t tile, uint32_t* __restrict__ lists)
+                                                const CameraParams& cam, float slack, float margin_px, uint32_t tile, uint32_t* __restrict__ lists)
 {
     uint32_t* rec = lists + (size_t)tile * kBeamRecord;
     const PixelRef pr = slot_to_pixel(pm, tile << 6);  // the block's first pixel
     uint32_t count = 0;
     if (pr.valid) {
-        const Beam b = make_beam(cam, pr.px, pr.py, slack);
+        const Beam b = make_beam(cam, pr.px, pr.py, slack, margin_px);
         if (sv.n == 1) {
             rec[1] = ids[0];
             count = 1;
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(256) void beam_kernel(SceneView sv, PixelMap pm, Fr
     }
     stack += threadIdx.x;
     for (uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x; tile < n_blocks; tile += gridDim.x * blockDim.x)
-        beam_walk_block<StackT>(sv, nodes, ids, stack, stride, pm, fp.cam, slack, tile, lists);
+        beam_walk_block<StackT>(sv, nodes, ids, stack, stride, pm, fp.cam, slack, 0.0f, tile, lists);
 }
 
 // Closest hit of a primary ray over its block's candidate list (wave-uniform loop; sphere records come through the scalar
@@ -973,7 +975,10 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
         if (j < job.n_blocks) {
             CameraParams cam_b = cold_arg<CameraParams>(offsetof(BounceArgHead, fp) + offsetof(FrameParams, cam));
             cam_b.Position = make_f3(job.centre[0], job.centre[1], job.centre[2]);
-            beam_walk_block<StackT>(sv, nodes, ids, stack, blockDim.x, cold_arg<PixelMap>(offsetof(BounceArgHead, pm)), cam_b, job.slack, job.first_block + j, job.lists);
+            cam_b.Right = make_f3(job.right[0], job.right[1], job.right[2]);  // (the orientation the lists are made for: this frame's, or one extrapolated from a turn)
+            cam_b.Up = make_f3(job.up[0], job.up[1], job.up[2]);
+            cam_b.Forward = make_f3(job.forward[0], job.forward[1], job.forward[2]);
+            beam_walk_block<StackT>(sv, nodes, ids, stack, blockDim.x, cold_arg<PixelMap>(offsetof(BounceArgHead, pm)), cam_b, job.slack, job.margin_px, job.first_block + j, job.lists);
         }
     }
     // Work distribution: a static grid-stride over the batches -- except for the looping pass behind a segmented hand-over,

@@ -11,6 +11,7 @@ run() { echo "== $*" >&2; python3 bench.py "$@" 2>/dev/null | tail -1 >> $OUT; }
 run --scene small --width 256 --height 256 --bounces 4 --steps 300 --warmup 30                      # C1
 run --steps 300 --warmup 30                                                                           # C2 (headline)
 run --steps 300 --warmup 30 --moving-camera --no-cpu-baseline                                         # C2 under a camera that moves every frame (App.cpp:531-553)
+run --steps 300 --warmup 30 --turning-camera --no-cpu-baseline                                        # C2 under a camera that turns every frame (mouse look)
 run --steps 300 --warmup 30 --animate --no-cpu-baseline                                               # C2 animated (N2)
 run --steps 300 --warmup 30 --textures --no-cpu-baseline                                              # C2 textured (N1)
 run --steps 300 --warmup 30 --env-map --no-cpu-baseline                                               # C2 lit by the lat-long environment map (a18)

@@ -487,3 +487,39 @@ def test_moving_camera_frames_in_flight_match_per_ray_traversal(dxrs, host, rend
     assert out["beams"][1] == out["plain"][1]
     for k in range(n):
         assert np.array_equal(out["beams"][0][k], out["plain"][0][k]), k
+
+
+def test_primary_beam_lists_follow_a_turning_camera(dxrs, host, oracle, renderer):
+    """A camera that turns slowly (App::Update's mouse look) keeps primary-beam lists too: they are built for the orientation extrapolated a few
+    frames ahead, every block's outline widened by the pixels a ray's crossing of the image can move within the turn the lists are to cover
+    (make_beam margin_px; pt_api.hip beam_cache_lookup bounds the displacement at the image corner).  Whole frames against the oracle -- the
+    corners are where the bound is tightest -- while the camera yaws, pitches, rolls about a moving position, and turns too fast for any list."""
+    import math
+    from util import count_mismatch
+    spheres, materials, sd = host.scene(dxrs.host.SCENE_DEMO, seed=0)
+    w, h = 320, 200
+    gs = dxrs.types.graphics_settings(w, h, frame_index=0, bounces=3, spp=1)
+    renderer.set_scene(spheres, materials, sd)
+    used = []
+
+    def frame(k, position, look_at):
+        gs.FrameIndex = k
+        cam = host.camera(w, h, position=position, look_at=look_at, jitter_index=k % 8)
+        renderer.set_constants(gs); renderer.set_camera(cam)
+        img, st = renderer.render()
+        ref, ost = oracle.render(spheres, materials, sd, cam, gs, threads=8)
+        assert st.rays == ost.rays and count_mismatch(img, ref) == 0, (k, position, look_at)
+        used.append(bool(st.beams_used))
+
+    for k in range(16):                                    # a slow yaw about a fixed position
+        frame(k, (0.0, 1.0, -14.0), (0.004 * k, 0.0, 0.0))
+    assert sum(used[3:]) >= 10, used
+    n0 = len(used)
+    for k in range(16, 32):                                # yaw + pitch while the camera also travels
+        j = k - 16
+        frame(k, (0.003 * j, 1.0 + 0.002 * j, -14.0 + 0.004 * j), (0.06 + 0.003 * j, 0.002 * j, 0.0))
+    assert sum(used[n0 + 4:]) >= 8, used
+    n1 = len(used)
+    for k in range(32, 38):                                # a fast turn: no list can be worth its margin
+        frame(k, (0.05, 1.03, -13.94), (0.1 + 0.5 * (k - 31), 0.03, 0.0))
+    assert not any(used[n1 + 1:]), used

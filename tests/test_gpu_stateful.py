@@ -63,7 +63,7 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
     from dxrs_amd import abi_types as A
     flags = (0, 0, A.PT_FLAG_SPLIT_KERNELS, A.PT_FLAG_FAST_BUILD, A.PT_FLAG_NO_LDS_SCENE, A.PT_FLAG_NO_LDS_SCENE | A.PT_FLAG_FAST_BUILD)[(seed // 3) % 6]
     r = dxrs.Renderer(stream=tstream.cuda_stream, frames_in_flight=lanes, flags=flags)
-    state = dict(spheres=None, materials=None, sd=None, tex=None, w=64, h=48, spp=1, bounces=4, di=False, cam_seed=0, pos=(0.0, 0.5, -12.0), frame=0, vel=None)
+    state = dict(spheres=None, materials=None, sd=None, tex=None, w=64, h=48, spp=1, bounces=4, di=False, cam_seed=0, pos=(0.0, 0.5, -12.0), frame=0, vel=None, orbit=False)
     checked = 0
     log = []
     expected = dict(rays=0)  # what the device-accumulated ray total must read (checked and reset around every tile frame and at the end)
@@ -161,7 +161,8 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
         gs = dxrs.types.graphics_settings(w, h, frame_index=state["frame"], bounces=state["bounces"], spp=state["spp"], di=state["di"])
         if state["vel"] is not None:  # drifting: the camera translates a little every frame and does not turn (primary-beam lists with slack)
             state["pos"] = tuple(float(np.float32(p + v)) for p, v in zip(state["pos"], state["vel"]))
-        cam = host.camera(w, h, position=state["pos"], look_at=None if state["vel"] is not None else (0.0, 0.0, 0.0), jitter_index=state["cam_seed"])
+        # (drifting with the eye on the origin = a slow turn on top of the travel: lists with slack AND a pixel margin; else the orientation stays)
+        cam = host.camera(w, h, position=state["pos"], look_at=None if (state["vel"] is not None and not state["orbit"]) else (0.0, 0.0, 0.0), jitter_index=state["cam_seed"])
         state["frame"] += 1
         r.set_camera(cam); r.set_constants(gs)
         mode = rng.integers(0, 4)
@@ -253,8 +254,9 @@ def test_random_call_sequences_match_oracle(dxrs, host, oracle, seed):
                     state.update(pos=(float(rng.uniform(-2, 2)), float(rng.uniform(0, 2)), float(rng.uniform(-14, -9))), cam_seed=int(rng.integers(0, 64)), vel=None)
                 elif op >= 13:  # start (or change) a drift: a steady translation of a few thousandths per frame, or none at all for a while
                     v = rng.normal(size=3) * float(rng.choice([0.0, 0.002, 0.004, 0.02]))
-                    log.append(f"drift {v}")
-                    state.update(vel=tuple(float(x) for x in v))
+                    orbit = bool(rng.random() < 0.5)
+                    log.append(f"drift {v} orbit={orbit}")
+                    state.update(vel=tuple(float(x) for x in v), orbit=orbit)
                 render()
             check_totals()
     finally:
@@ -291,7 +293,7 @@ def test_pipelined_sequences_match_oracle(dxrs, host, oracle, seed):
                 r.set_textures(ts)
             bufs = [torch.empty((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(lanes)]
             torch.cuda.synchronize()
-            pos, cam_seed, vel = (0.0, 0.5, -12.0), 0, None
+            pos, cam_seed, vel, orbit = (0.0, 0.5, -12.0), 0, None, False
             snaps, frames = [], []
             for k in range(14):
                 what = int(rng.integers(0, 8))
@@ -310,10 +312,11 @@ def test_pipelined_sequences_match_oracle(dxrs, host, oracle, seed):
                     pos, cam_seed, vel = (float(rng.uniform(-1, 1)), float(rng.uniform(0, 1.5)), float(rng.uniform(-13, -10))), int(rng.integers(0, 64)), None
                 elif what >= 6:  # the camera starts to drift: a steady translation without a turn (beam lists with slack, built behind a frame on its lane)
                     vel = tuple(float(x) for x in rng.normal(size=3) * float(rng.choice([0.002, 0.005])))
+                    orbit = bool(rng.random() < 0.5)  # the eye stays on the origin: a slow turn on top of the travel (lists with a pixel margin, too)
                 if vel is not None:
                     pos = tuple(float(np.float32(p + v)) for p, v in zip(pos, vel))
                 gs = dxrs.types.graphics_settings(w, h, frame_index=k, bounces=int(rng.choice([2, 5])), spp=int(rng.choice([1, 1, 2])), di=bool(rng.random() < 0.3))
-                cam = host.camera(w, h, position=pos, look_at=None if vel is not None else (0.0, 0.0, 0.0), jitter_index=cam_seed)
+                cam = host.camera(w, h, position=pos, look_at=None if (vel is not None and not orbit) else (0.0, 0.0, 0.0), jitter_index=cam_seed)
                 r.set_camera(cam); r.set_constants(gs)
                 r.render_device(bufs[k % lanes].data_ptr())
                 snaps.append(bufs[k % lanes].clone())  # on the caller's stream: after frame k, before the frame that reuses the buffer
