@@ -168,10 +168,11 @@ struct PtContext {
     uint32_t tot_beam_frames = 0;  // frames since the last reset whose primary pass used the primary-beam lists
 
     // Primary beams (DESIGN.md "Primary beams"): per-8x8-block candidate sphere lists for the primary pass.  They depend on the
-    // camera's orientation, the frame geometry and the scene, and on the camera's POSITION up to the slack they were built with
-    // (Beam::slack) -- not on the frame index or the jitter (the beams are a pixel wider than the blocks).  A view that RESTS gets
-    // lists with no slack on its second frame (one launch on a side stream); a camera that moves without turning gets lists
-    // centred some frames ahead of it with a slack of a few frames' travel, built in shares inside the frames' own primary passes
+    // camera's lens, the frame geometry and the scene, on the camera's POSITION up to the slack (Beam::slack) and on its ORIENTATION
+    // up to the pixel margin (make_beam) they were built with -- not on the frame index or the jitter (the beams are a pixel wider
+    // than the blocks).  A view that RESTS gets exact lists on its second frame (one launch on a side stream); a camera that
+    // travels and turns gets lists centred and oriented some frames ahead of it, with a slack of a few frames' travel and a margin
+    // of a few frames' turn, built in shares inside the frames' own primary passes
     // while the frames use the previous ones -- a frame never waits for a build of the moving kind: it takes the newest lists that
     // are readable and hold for its pose, or traverses per ray.
     struct BeamLists {

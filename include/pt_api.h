@@ -102,7 +102,7 @@ typedef struct PtStats {
     double ms_tail;             /* device time of the fused tail launch (0 unless profiling on) */
     uint32_t tail_launches;
     uint32_t beams_used;        /* pt_render*: 1 = the primary pass took its candidates from primary-beam lists (the exact ones of a resting
-                                   view, or the ones with slack that follow a camera translating without a turn -- DESIGN.md "Primary beams");
+                                   view, or the widened ones that follow a camera travelling and turning smoothly -- DESIGN.md "Primary beams");
                                    pt_get_totals: the number of such frames since the last reset */
     uint64_t rays_first_pass_inline; /* pt_get_totals only: secondary rays the primary passes traced in registers (the first
                                         bounce of a 1-spp frame never enters a queue); part of `rays` */
