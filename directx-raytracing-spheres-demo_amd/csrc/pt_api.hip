@@ -42,7 +42,7 @@ struct EventPair {
 struct Knobs {
     int split = -1, traverse_blocks_per_cu = -1, fused_threads = -1, no_adaptive_grid = -1, shade_blocks_per_cu = -1, tail_threshold = -1,
         tail_blocks_per_cu = -1, loop_threads = -1, inline2_min_slots = -1, tail_after = -1, seg = -1, loop_use_tail = -1, fuse_loop = -1,
-        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1, lane_priority = -1, fused_refit = -1, beam_reach = -1, beam_max_slack_pct = -1, beam_max_margin = -1;
+        ray_replacement = -1, dyn_blocks_per_cu = -1, debug_counts = -1, sah = -1, sah_max_spheres = -1, beams = -1, wide = -1, descent = -1, roctx = -1, lane_priority = -1, fused_refit = -1, beam_reach = -1, beam_max_slack_pct = -1, beam_max_margin = -1, beam_share_wgs = -1;
 };
 
 // Per-frame-in-flight state (see PtContext::lanes).
@@ -533,7 +533,7 @@ Knobs read_knobs()
     k.no_adaptive_grid = std::getenv("PT_NO_ADAPTIVE_GRID") ? 1 : -1; k.shade_blocks_per_cu = env_knob("PT_SHADE_BLOCKS_PER_CU");
     k.tail_threshold = env_knob("PT_TAIL_THRESHOLD"); k.tail_blocks_per_cu = env_knob("PT_TAIL_BLOCKS_PER_CU"); k.loop_threads = env_knob("PT_LOOP_THREADS");
     k.inline2_min_slots = env_knob("PT_INLINE2_MIN_SLOTS"); k.tail_after = env_knob("PT_TAIL_AFTER"); k.seg = env_knob("PT_SEG");
-    k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.beam_reach = env_knob("PT_BEAM_REACH"); k.beam_max_slack_pct = env_knob("PT_BEAM_MAX_SLACK_PCT"); k.beam_max_margin = env_knob("PT_BEAM_MAX_MARGIN"); k.lane_priority = env_knob("PT_LANE_PRIORITY"); k.fused_refit = env_knob("PT_FUSED_REFIT"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
+    k.loop_use_tail = std::getenv("PT_LOOP_USE_TAIL") ? 1 : -1; k.fuse_loop = env_knob("PT_FUSE_LOOP"); k.beam_reach = env_knob("PT_BEAM_REACH"); k.beam_max_slack_pct = env_knob("PT_BEAM_MAX_SLACK_PCT"); k.beam_max_margin = env_knob("PT_BEAM_MAX_MARGIN"); k.beam_share_wgs = env_knob("PT_BEAM_SHARE_WGS"); k.lane_priority = env_knob("PT_LANE_PRIORITY"); k.fused_refit = env_knob("PT_FUSED_REFIT"); k.ray_replacement = env_knob("PT_RAY_REPLACEMENT");
     k.dyn_blocks_per_cu = env_knob("PT_DYN_BLOCKS_PER_CU"); k.debug_counts = std::getenv("PT_DEBUG_COUNTS") ? 1 : -1; k.sah = env_knob("PT_SAH");
     k.sah_max_spheres = env_knob("PT_SAH_MAX_SPHERES"); k.beams = env_knob("PT_BEAMS"); k.wide = env_knob("PT_WIDE"); k.descent = env_knob("PT_DESCENT"); k.roctx = env_knob("PT_ROCTX");
     return k;
@@ -1010,8 +1010,10 @@ PtStatus render_common(PtContext* c, const PixelMap& pm, uint64_t valid_pixels, 
     BeamJob beam_job{};
     if (!split && !L.scene_private && c->n_nodes > 0 && knob_or(c->knobs.beams, 1u) != 0 && std::fabs(c->cam.Jitter[0]) <= 0.5f && std::fabs(c->cam.Jitter[1]) <= 0.5f) {
         hipEvent_t beam_wait = nullptr;
-        // (a share of a build rides on the first wave of up to 32 workgroups of the primary pass, 64 blocks each)
-        if ((st = beam_cache_lookup(c, pm, std::min(primary_grid, 32u) * 64u, &beam_lists, &beam_wait, &beam_job)) != PT_OK) return st;
+        // (a share of a build rides on the first wave of up to PT_BEAM_SHARE_WGS = 128 workgroups of the primary pass, 64 blocks each: four frames'
+        // shares make a 1080p build -- 32 left a camera that travels AND turns without lists for a sixth of its frames, the whole build in one
+        // frame costs that frame 1 %)
+        if ((st = beam_cache_lookup(c, pm, std::min(primary_grid, knob_or(c->knobs.beam_share_wgs, 128u)) * 64u, &beam_lists, &beam_wait, &beam_job)) != PT_OK) return st;
         if (beam_wait) PT_HIP(c, hipStreamWaitEvent(L.stream, beam_wait, 0));
     } else {
         c->beam.last_key.clear();

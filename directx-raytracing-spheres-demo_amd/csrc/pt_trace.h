@@ -966,7 +966,7 @@ __global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(4
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t my_rays = 0;
     // A share of the NEXT primary-beam lists of a moving camera (FrameParams::beam_job, pt_api.hip beam_cache_lookup): the first wave of the
-    // first workgroups walks 64 blocks' pyramids each, one lane per block, before it joins its workgroup's tiles -- a 2048-block share per
+    // first workgroups walks 64 blocks' pyramids each, one lane per block, before it joins its workgroup's tiles -- an 8192-block share per
     // frame hides in the pass (its other waves take the tiles meanwhile), where a whole build as a launch of its own stalled a lane for 60 us
     // and put the three lanes out of step for several frames (tools/experiments/moving_trace.sh).
     if (kPrimary && !kLoop && wave == 0) {
