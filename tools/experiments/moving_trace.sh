@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export PT_BEAM_REACH=${1:-32}
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/moving_trace -o k -- python3 $R/bench.py --steps 200 --warmup 10 --prewarm 0 --moving-camera --no-cpu-baseline --no-roofline > $R/gpurun_out/moving_trace.json 2> $R/gpurun_out/moving_trace.err
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/moving_trace -o k -- python3 $R/bench.py --steps 200 --warmup 10 --prewarm 0 ${PT_TRACE_FLAGS---moving-camera} --no-cpu-baseline --no-roofline > $R/gpurun_out/moving_trace.json 2> $R/gpurun_out/moving_trace.err
 python3 - <<'PY'
 import csv, os, collections
 R = os.environ["GRAFT_REPO_ROOT"]
